@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the GENUINE reference (build container only).
+
+TEST INFRASTRUCTURE.  Needs /root/reference: `make -C oracle` compiles the reference's own
+sources into oracle/_ref/ (nothing is copied), oracle/_ref/ref_harness then drives the
+reference's exported C API and each example's own main().  What is committed is data only:
+
+  tests/golden/orig/*.frirlrb.txt     mirror of the reference's own golden rule bases
+                                      (reference tests/orig/, the only known-answer files it ships)
+  tests/golden/ref_<env>.frirlrb.txt  final rule base of the reference compiled HERE (construct mode)
+  tests/golden/ref_<env>.trace.jsonl  first 400 steps, one record per episode and a running
+                                      FNV-1a hash over every step of the whole run
+  tests/golden/vec_<env>.jsonl        function-level vectors (tables, index snap, rule distance,
+                                      vag_concl, weights, best action, SARSA updates, env steps)
+                                      on the rule base reached after a few episodes
+  tests/golden/synth_*.jsonl          hashes for large synthetic rule bases (inputs are re-created
+                                      in the tests by oracle orc_synth_*; nant <= 8 only, the
+                                      reference's cap is FIVE_MAX_NUM_OF_UNIVERSES = 8)
+"""
+import os, shutil, subprocess, sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("FRIRL_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+ENVS = ["mountaincar", "cartpole", "acrobot"]
+VEC_EPISODES = {"mountaincar": 6, "cartpole": 9, "acrobot": 5}
+SYNTH = [  # nant, U, R, A, seed, nq
+    (3, 41, 33, 3, 11, 64),
+    (5, 41, 367, 3, 12, 64),
+    (5, 1001, 4096, 21, 13, 48),
+    (8, 101, 4096, 0, 14, 32),
+    (5, 41, 65536, 3, 15, 16),
+    (3, 41, 8192, 3, 16, 24),
+]
+
+
+def run(*cmd, **kw):
+    print("+", " ".join(cmd))
+    subprocess.run(cmd, check=True, **kw)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not found: golden vectors can only be regenerated in the build container")
+    run("make", "-C", HERE)
+    os.makedirs(os.path.join(GOLD, "orig"), exist_ok=True)
+    for e in ENVS:
+        shutil.copyfile(os.path.join(REF, "tests", "orig", f"frirl_example_{e}.frirlrb.txt"),
+                        os.path.join(GOLD, "orig", f"frirl_example_{e}.frirlrb.txt"))
+    tmp = "/tmp/frirl_golden"
+    os.makedirs(tmp, exist_ok=True)
+    for e in ENVS:
+        with open(os.path.join(tmp, f"{e}.stdout"), "w") as so:
+            run(HARNESS, "demo", e, tmp, stdout=so)
+        shutil.copyfile(os.path.join(tmp, f"{e}.frirlrb.txt"), os.path.join(GOLD, f"ref_{e}.frirlrb.txt"))
+        shutil.copyfile(os.path.join(tmp, f"{e}.trace.jsonl"), os.path.join(GOLD, f"ref_{e}.trace.jsonl"))
+        with open(os.path.join(tmp, f"{e}.vstdout"), "w") as so:
+            run(HARNESS, "vectors", e, os.path.join(GOLD, f"vec_{e}.jsonl"), str(VEC_EPISODES[e]), stdout=so)
+    for (nant, U, R, A, seed, nq) in SYNTH:
+        run(HARNESS, "synth", str(nant), str(U), str(R), str(A), str(seed), str(nq),
+            os.path.join(GOLD, f"synth_n{nant}_u{U}_r{R}.jsonl"))
+    sz = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(GOLD) for f in fs)
+    print(f"golden fixtures: {sz / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
