@@ -1,0 +1,100 @@
+// device_common.h -- shared device helpers of the gfx950 FRIRL/FIVE kernels.
+// CDNA4 only: 64-lane wavefronts, 256-thread workgroups (4 waves, one per SIMD).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/frirl_hip.h"
+
+#define FRIRL_WAVE 64
+#define FRIRL_BLOCK 256
+#define FRIRL_WAVES_PER_BLOCK (FRIRL_BLOCK / FRIRL_WAVE)
+
+namespace frirl {
+
+// Nearest index on a fixed-step universe -- reference src/inl/min.inl:71-92
+// (get_vag_abs_min_i_fixres): C truncation of (point - u[0]) / div, clamp, then the nearer of
+// u[low], u[low+1] with ties to `low`.  The reference's read of u[low+1] one past the row when
+// low == len-1 is guarded here (preserve the result, not the stray read).
+__device__ __forceinline__ unsigned snap_index(const double *__restrict__ uni, int len, double point, double div)
+{
+    const int low = (int)((point - uni[0]) / div);
+    if (low < 0) return 0u;
+    if (low >= len) return (unsigned)(len - 1);
+    if (low + 1 >= len) return (unsigned)low;
+    const double d1 = uni[low] - point;
+    const double d2 = uni[low + 1] - point;
+    return (fabs(d1) <= fabs(d2)) ? (unsigned)low : (unsigned)(low + 1);
+}
+
+// Step of universe k -- reference src/five/FIVEInit.c:244-248 (udivs = (u_last - u_first) / (U-1)).
+__device__ __forceinline__ double universe_div(const double *__restrict__ uni, int U)
+{
+    return (uni[U - 1] - uni[0]) / (double)(U - 1);
+}
+
+// VE value of the observation in dimension k: ve[k][snap(x_k)]  (five_rule_distance.c:75,80).
+__device__ __forceinline__ double observe_ve(const double *__restrict__ u, const double *__restrict__ ve, int U, int k, double xk)
+{
+    const double *uni = u + (size_t)k * U;
+    return ve[(size_t)k * U + snap_index(uni, U, xk, universe_div(uni, U))];
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off, FRIRL_WAVE);
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+// Block-wide minimum (all threads get the result); `scratch` holds FRIRL_WAVES_PER_BLOCK words.
+__device__ __forceinline__ unsigned block_min_u32(unsigned v, unsigned *scratch)
+{
+    v = wave_min_u32(v);
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    unsigned m = scratch[0];
+#pragma unroll
+    for (int w = 1; w < FRIRL_WAVES_PER_BLOCK; w++) m = (scratch[w] < m) ? scratch[w] : m;
+    __syncthreads();
+    return m;
+}
+
+// Fixed-shape sum: butterfly inside the wave (every lane ends with the same bits), then the
+// wave partials are added in wave order.  Deterministic run to run; no float atomics.
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off, FRIRL_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum_f64(double v, double *scratch)
+{
+    v = wave_sum_f64(v);
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double s = scratch[0];
+#pragma unroll
+    for (int w = 1; w < FRIRL_WAVES_PER_BLOCK; w++) s = s + scratch[w];
+    __syncthreads();
+    return s;
+}
+
+}  // namespace frirl
+
+// ---- host-side helpers shared by the extern "C" entry points ---------------------------------
+namespace frirl_host {
+void set_error(const char *fmt, ...);
+int check_device();                       // 0 or FRIRL_HIP_ENODEV
+int check_launch(const char *what);       // hipGetLastError -> code
+int check_tables(const frirl_hip_tables *t);
+int check_rulebases(const frirl_hip_tables *t, const frirl_hip_rulebases *b);
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace frirl_host

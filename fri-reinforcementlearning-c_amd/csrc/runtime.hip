@@ -1,0 +1,101 @@
+// runtime.hip -- device discovery, error reporting and argument checks of libfrirl_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "device_common.h"
+
+namespace frirl_host {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int check_device()
+{
+    static thread_local int cached = 1;   // 1 = unknown
+    if (cached != 1) return cached;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no usable HIP device (%s): the FRIRL hot path has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return FRIRL_HIP_ENODEV;          // not cached: a device may appear (tests without GPU stay ENODEV)
+    }
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        set_error("hipGetDeviceProperties failed");
+        return FRIRL_HIP_ENODEV;
+    }
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", dev, p.gcnArchName);
+        return FRIRL_HIP_ENODEV;
+    }
+    cached = FRIRL_HIP_OK;
+    return cached;
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return FRIRL_HIP_ELAUNCH;
+    }
+    return FRIRL_HIP_OK;
+}
+
+int check_tables(const frirl_hip_tables *t)
+{
+    if (!t || !t->u || !t->ve) { set_error("tables: NULL pointer"); return FRIRL_HIP_EINVAL; }
+    if (t->nant < 1 || t->nant > FRIRL_HIP_MAX_NANT) { set_error("tables: nant=%d outside 1..%d", t->nant, FRIRL_HIP_MAX_NANT); return FRIRL_HIP_EINVAL; }
+    if (t->U < 2) { set_error("tables: U=%d < 2", t->U); return FRIRL_HIP_EINVAL; }
+    return FRIRL_HIP_OK;
+}
+
+int check_rulebases(const frirl_hip_tables *t, const frirl_hip_rulebases *b)
+{
+    int rc = check_tables(t);
+    if (rc) return rc;
+    if (!b || !b->rb || !b->nrules) { set_error("rulebases: NULL pointer"); return FRIRL_HIP_EINVAL; }
+    if (b->E < 1) { set_error("rulebases: E=%d < 1", b->E); return FRIRL_HIP_EINVAL; }
+    if (b->maxR < 2 || (b->maxR & 1)) { set_error("rulebases: maxR=%d must be even and >= 2 (16-byte vector loads)", b->maxR); return FRIRL_HIP_EINVAL; }
+    if (reinterpret_cast<uintptr_t>(b->rb) & 15) { set_error("rulebases: rb must be 16-byte aligned"); return FRIRL_HIP_EINVAL; }
+    return FRIRL_HIP_OK;
+}
+
+}  // namespace frirl_host
+
+extern "C" {
+
+const char *frirl_hip_version(void) { return "frirl-hip 0.1 (gfx950)"; }
+
+const char *frirl_hip_last_error(void) { return frirl_host::g_err; }
+
+int frirl_hip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); frirl_host::set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return FRIRL_HIP_ENODEV; }
+    return n;
+}
+
+int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, int64_t *hbm_bytes)
+{
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) { (void)hipGetLastError(); frirl_host::set_error("hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e)); return FRIRL_HIP_ENODEV; }
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (cus) *cus = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return FRIRL_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/frirl_hip.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import frirl_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    frirl_amd.build()
+    return frirl_amd.lib()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "frirl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:five|frirl)_hip_\w+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = declared_functions()
+    assert "five_hip_rule_distance" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/frirl_hip.h but not exported by libfrirl_hip.so"
+    assert set(frirl_amd.SIGNATURES) == set(names), "python binding and header disagree on the ABI surface"
+
+
+def test_code_object_is_gfx950(lib):
+    blob = open(frirl_amd.HIP_LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(frirl_amd.Tables) == 24 and frirl_amd.Tables.u.offset == 8 and frirl_amd.Tables.ve.offset == 16
+    assert C.sizeof(frirl_amd.RuleBases) == 24 and frirl_amd.RuleBases.rb.offset == 8 and frirl_amd.RuleBases.nrules.offset == 16
+
+
+def test_argument_validation_and_no_cpu_fallback(lib):
+    import torch
+    t = frirl_amd.Tables(3, 41, 0, 0)
+    b = frirl_amd.RuleBases(1, 8, 0, 0)
+    rc = lib.five_hip_rule_distance(C.byref(t), C.byref(b), None, None, None, None)
+    assert rc == -2 and b"NULL" in lib.frirl_hip_last_error()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the ENODEV path is exercised on CPU-only hosts")
+    buf = (C.c_double * 4096)()
+    addr = (C.addressof(buf) + 15) & ~15
+    t = frirl_amd.Tables(3, 41, addr, addr)
+    b = frirl_amd.RuleBases(1, 8, addr, addr)
+    rc = lib.five_hip_rule_distance(C.byref(t), C.byref(b), addr, addr, addr, None)
+    assert rc == -1, "without a GPU the hot path must fail loudly (FRIRL_HIP_ENODEV), never compute on the CPU"
+    assert b"no CPU fallback" in lib.frirl_hip_last_error()
+    assert lib.frirl_hip_device_count() <= 0
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    monkeypatch.setattr(frirl_amd, "_lib", None)
+    monkeypatch.setattr(frirl_amd, "HIP_LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(frirl_amd.FrirlHipError):
+        frirl_amd.lib()
