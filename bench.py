@@ -83,7 +83,7 @@ def cpu_baseline(w):
     nant, U, R = w["nant"], w["U"], w["R"]
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if os.path.exists(harness) and nant <= 8:
-        nq = max(64, int(3.0e9 / R))
+        nq = max(64, int(2.0e10 / R))
         t0 = time.time()
         out = subprocess.run([harness, "bench", str(nant), str(U), str(R), str(nq)], check=True, capture_output=True, text=True).stdout
         rec = json.loads(out.strip().splitlines()[-1])
@@ -183,6 +183,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_ms},
         }
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
+            if tr and not args.envs:
+                out["roofline"]["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
+                out["roofline"]["traffic_source"] = tr["source"]
+        except (OSError, ValueError):
+            pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -60,6 +60,10 @@ def lib():
         if not os.path.exists(HIP_LIB_PATH):
             raise FrirlHipError(f"{HIP_LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; "
                                 "the FRIRL hot path has no CPU fallback")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Loaded
+        # first, it satisfies this library's NEEDED entry, so kernels, streams and events all live in the
+        # runtime torch uses.  (A plain C host links /opt/rocm's runtime and never sees torch.)
+        import torch  # noqa: F401
         L = C.CDLL(HIP_LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError if the library lacks a declared symbol

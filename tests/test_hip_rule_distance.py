@@ -42,7 +42,8 @@ def test_rule_distance_bit_exact(nant, U, R, E, A):
     d_ref, hit_ref = b.oracle_rule_distance(x)
     d, hit = run_case(b, x)
     assert (hit.astype(np.int64) == hit_ref.astype(np.int64)).all(), "exact-hit index (lowest r < nrules with d == 0, else -1)"
-    assert (hit_ref >= 0).any() and (hit_ref < 0).any()
+    if E >= 8:
+        assert (hit_ref >= 0).any() and (hit_ref < 0).any()
     for e in range(E):
         n = int(b.nrules[e])
         assert (bits(d[e, :n]) == bits(d_ref[e, :n])).all(), f"env {e}: distances must be bit-identical"
