@@ -33,6 +33,25 @@ class RuleBases(C.Structure):
     _fields_ = [("E", C.c_int32), ("maxR", C.c_int32), ("rb", C.c_void_p), ("nrules", C.c_void_p)]
 
 
+MAX_GRID = 64
+ENV_KINDS = {"mountaincar": 0, "cartpole": 1, "acrobot": 2}
+UPD_INACTIVE, UPD_EXACT, UPD_SPREAD, UPD_INSERTED, UPD_SKIPPED, UPD_FULL = range(6)
+
+
+class AgentDesc(C.Structure):
+    """struct frirl_hip_agent (include/frirl_hip.h)."""
+    _fields_ = [("alpha", C.c_double), ("gamma", C.c_double), ("qdiff_pos_boundary", C.c_double), ("qdiff_neg_boundary", C.c_double),
+                ("weight_significant", C.c_double), ("skip_rules", C.c_int32), ("p", C.c_int32), ("A", C.c_int32), ("env_kind", C.c_int32),
+                ("max_steps", C.c_int32), ("reserved", C.c_int32), ("grid_len", C.c_int32 * MAX_NANT), ("grid_div", C.c_double * MAX_NANT),
+                ("values_def", C.c_double * MAX_NANT), ("grid_values", C.c_void_p), ("action_ve", C.c_void_p)]
+
+
+class EnvsDesc(C.Structure):
+    """struct frirl_hip_envs (include/frirl_hip.h)."""
+    _fields_ = [("states", C.c_void_p), ("q_ant", C.c_void_p), ("fus", C.c_void_p), ("done", C.c_void_p), ("ep_steps", C.c_void_p),
+                ("ep_reward", C.c_void_p), ("rant", C.c_void_p), ("status", C.c_void_p)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/frirl_hip.h declares
@@ -42,6 +61,18 @@ SIGNATURES = {
     "frirl_hip_device_count": (C.c_int, []),
     "frirl_hip_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "five_hip_rule_distance": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "five_hip_vag_concl": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "five_hip_vag_concl_weight": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frirl_hip_get_best_action": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "five_hip_add_rule": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "frirl_hip_update_sarsa": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frirl_hip_env_step": (C.c_int, [C.POINTER(AgentDesc), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "frirl_hip_episode_begin": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
+    "frirl_hip_episode_step": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
 }
 
 
@@ -113,3 +144,115 @@ class Problem:
                                           _ptr(ruledists) if materialise else None, _ptr(hit), _stream(stream))
         check(rc, "five_hip_rule_distance")
         return (ruledists if materialise else None), hit
+
+    def vag_concl(self, x, p=0, stream=None):
+        """five_hip_vag_concl: (conc [E] float64, hit [E] int32 with -1 = interpolated)."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float64 and x.shape == (self.E, self.nant) and x.is_contiguous()
+        conc = torch.empty((self.E,), dtype=torch.float64, device=x.device)
+        hit = torch.empty((self.E,), dtype=torch.int32, device=x.device)
+        check(lib().five_hip_vag_concl(C.byref(self.tables), C.byref(self.bases), p, _ptr(x), _ptr(conc), _ptr(hit), _stream(stream)),
+              "five_hip_vag_concl")
+        return conc, hit
+
+    def vag_concl_weight(self, x, p=0, weights=None, stream=None):
+        """five_hip_vag_concl_weight: (weights [E,maxR], hit [E]); rows of exact-hit environments are untouched."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float64 and x.shape == (self.E, self.nant) and x.is_contiguous()
+        if weights is None:
+            weights = torch.full((self.E, self.maxR), float("nan"), dtype=torch.float64, device=x.device)
+        hit = torch.empty((self.E,), dtype=torch.int32, device=x.device)
+        check(lib().five_hip_vag_concl_weight(C.byref(self.tables), C.byref(self.bases), p, _ptr(x), _ptr(weights), _ptr(hit),
+                                              _stream(stream)), "five_hip_vag_concl_weight")
+        return weights, hit
+
+    def get_best_action(self, states, action_ve, p=0, stream=None):
+        """frirl_hip_get_best_action: (actconc [E,A], best [E] int32)."""
+        import torch
+        assert states.is_cuda and states.dtype == torch.float64 and states.shape == (self.E, self.nant - 1) and states.is_contiguous()
+        A = action_ve.numel()
+        actconc = torch.empty((self.E, A), dtype=torch.float64, device=states.device)
+        best = torch.empty((self.E,), dtype=torch.int32, device=states.device)
+        check(lib().frirl_hip_get_best_action(C.byref(self.tables), C.byref(self.bases), p, _ptr(states), _ptr(action_ve), A,
+                                              _ptr(actconc), _ptr(best), _stream(stream)), "frirl_hip_get_best_action")
+        return actconc, best
+
+    def add_rule(self, rant, rconc, active=None, rant_store=None, stream=None):
+        """five_hip_add_rule: appends rant[e] -> rconc[e]; returns added [E] int32."""
+        import torch
+        added = torch.empty((self.E,), dtype=torch.int32, device=rant.device)
+        check(lib().five_hip_add_rule(C.byref(self.tables), C.byref(self.bases), _ptr(rant), _ptr(rconc), _ptr(active), _ptr(rant_store),
+                                      _ptr(added), _stream(stream)), "five_hip_add_rule")
+        return added
+
+
+class Agent:
+    """Host-side frirl_hip_agent: hyper-parameters + grids (device copies of the small tables are owned here)."""
+
+    def __init__(self, device, nant, grids, grid_div, values_def, action_ve, alpha, gamma, qdiff_pos, qdiff_neg, weight_thr=0.05,
+                 skip_rules=1, p=0, env_kind=0, max_steps=1000):
+        import numpy as np
+        import torch
+        assert len(grids) == nant and all(1 <= len(g) <= MAX_GRID for g in grids)
+        gv = np.zeros((nant, MAX_GRID))
+        for k, g in enumerate(grids):
+            gv[k, : len(g)] = g
+        self.grid_values = torch.from_numpy(gv).to(device)
+        self.action_ve = torch.as_tensor(np.asarray(action_ve, dtype=np.float64)).to(device)
+        self.A = len(grids[-1])
+        assert self.action_ve.numel() == self.A
+        d = AgentDesc()
+        d.alpha, d.gamma, d.qdiff_pos_boundary, d.qdiff_neg_boundary = alpha, gamma, qdiff_pos, qdiff_neg
+        d.weight_significant, d.skip_rules, d.p, d.A, d.env_kind, d.max_steps = weight_thr, skip_rules, p, self.A, env_kind, max_steps
+        for k in range(nant):
+            d.grid_len[k] = len(grids[k])
+            d.grid_div[k] = grid_div[k] if k < len(grid_div) else 0.0
+            d.values_def[k] = values_def[k] if k < len(values_def) else 0.0
+        d.grid_values, d.action_ve = self.grid_values.data_ptr(), self.action_ve.data_ptr()
+        self.desc, self.nant = d, nant
+
+
+class Envs:
+    """Device-resident per-environment episode state (struct frirl_hip_envs)."""
+
+    def __init__(self, problem, device, keep_rant=True, rant_init=None):
+        import torch
+        E, nant, maxR = problem.E, problem.nant, problem.maxR
+        self.states = torch.zeros((E, nant - 1), dtype=torch.float64, device=device)
+        self.q_ant = torch.zeros((E, nant), dtype=torch.float64, device=device)
+        self.fus = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.done = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.ep_steps = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.ep_reward = torch.zeros((E,), dtype=torch.float64, device=device)
+        self.status = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.rant = None
+        if keep_rant:
+            self.rant = torch.zeros((E, nant, maxR), dtype=torch.float64, device=device) if rant_init is None else rant_init
+        self.desc = EnvsDesc(self.states.data_ptr(), self.q_ant.data_ptr(), self.fus.data_ptr(), self.done.data_ptr(), self.ep_steps.data_ptr(),
+                             self.ep_reward.data_ptr(), self.rant.data_ptr() if self.rant is not None else None, self.status.data_ptr())
+
+
+def update_sarsa(problem, agent, envs, q_ant, reward, cur_q_ant, active=None, stream=None):
+    check(lib().frirl_hip_update_sarsa(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), _ptr(q_ant),
+                                       _ptr(reward), _ptr(cur_q_ant), _ptr(active), _stream(stream)), "frirl_hip_update_sarsa")
+
+
+def env_step(agent, action, states, stream=None):
+    import torch
+    E, ns = states.shape
+    new_states, q_states = torch.empty_like(states), torch.empty_like(states)
+    reward = torch.empty((E,), dtype=torch.float64, device=states.device)
+    success = torch.empty((E,), dtype=torch.int32, device=states.device)
+    check(lib().frirl_hip_env_step(C.byref(agent.desc), E, ns, _ptr(action), _ptr(states), _ptr(new_states), _ptr(reward), _ptr(success),
+                                   _ptr(q_states), _stream(stream)), "frirl_hip_env_step")
+    return new_states, reward, success, q_states
+
+
+def episode_begin(problem, agent, envs, stream=None):
+    check(lib().frirl_hip_episode_begin(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc),
+                                        _stream(stream)), "frirl_hip_episode_begin")
+
+
+def episode_step(problem, agent, envs, stream=None):
+    check(lib().frirl_hip_episode_step(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc),
+                                       _stream(stream)), "frirl_hip_episode_step")

@@ -31,11 +31,26 @@ def _stale(target, sources):
 
 def build_hip(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    if not force and not _stale(HIP_LIB, deps):
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if not force and not _stale(HIP_LIB, srcs + hdrs):
         return HIP_LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [HIPCC] + HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", HIP_LIB] + srcs
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in HIP_FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include")]
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print("+", " ".join(cmd))
+            jobs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, pr in jobs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in srcs]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
     if verbose:
         print("+", " ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,0 +1,374 @@
+// sarsa.hip -- SARSA rule update, rule append, environment step and the fused episode step.
+//
+// One workgroup owns one environment (its private rule base slab, episode state and sticky flags):
+// every decision of the reference's frirl_update_sarsa() is workgroup-uniform, so the whole TD step
+// -- Q(s',a'), Q(s,a), threshold test, grid snap, lookup of the snapped point, append or write-back --
+// runs inside one launch without inter-workgroup communication or atomics.
+#include "envs.h"
+#include "sweeps.h"
+
+namespace frirl {
+
+struct StepShared {
+    double q_ant[FRIRL_HIP_MAX_NANT];      // raw antecedent values of (s, a)
+    double cur_q_ant[FRIRL_HIP_MAX_NANT];  // raw antecedent values of (s', a')
+    double ve1[FRIRL_HIP_MAX_NANT];        // VE values of q_ant
+    double ve2[FRIRL_HIP_MAX_NANT];        // VE values of cur_q_ant
+    double rant[FRIRL_HIP_MAX_NANT];       // grid-snapped antecedents of a would-be new rule
+    double ve3[FRIRL_HIP_MAX_NANT];        // their VE values
+    double cur_states[FRIRL_HIP_MAX_NANT];
+    double reward;
+    int success;
+    int same;
+};
+
+// frirl_update_sarsa + update_rules (reference src/frirl/frirl_update_sarsa.c:348-385, :22-143).
+// `qp_known`: Q(s',a') already available (fused step: the greedy sweep produced it, identical
+// operands and order -- SURVEY 7(i)); otherwise it is computed by a sweep over ve2.
+template <int NANT, int BLOCK>
+__device__ int update_sarsa_block(const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ base,
+                                  int maxR, int32_t *nrules_e, const frirl_hip_agent &ag, StepShared &sh, double reward,
+                                  bool qp_known, double qp, int32_t *fus_e, double *rant_e, BlockRed<BLOCK> &red)
+{
+    const int R = *nrules_e;
+    const int p = ag.p > 0 ? ag.p : NANT;
+    double q1[NANT], q2[NANT];
+#pragma unroll
+    for (int k = 0; k < NANT; k++) { q1[k] = sh.ve1[k]; q2[k] = sh.ve2[k]; }
+    double *qcol = base + (size_t)NANT * maxR;
+
+    if (!qp_known) {                                                        // :356  Q(s',a')
+        const QResult rp = sweep_q<NANT, BLOCK>(base, maxR, R, q2, p, red);
+        qp = (rp.hit != FRIRL_HIP_NO_HIT) ? qcol[rp.hit] : rp.vagc / rp.ws;
+    }
+    const QResult rn = sweep_q<NANT, BLOCK>(base, maxR, R, q1, p, red);    // :357  Q(s,a)
+    const double qnow = (rn.hit != FRIRL_HIP_NO_HIT) ? qcol[rn.hit] : rn.vagc / rn.ws;
+    const double qdiff = ag.alpha * (reward + ag.gamma * qp - qnow);        // :358
+    int fus = *fus_e;
+    __syncthreads();   // every thread has read *fus_e / *nrules_e before thread 0 may rewrite them
+
+    if (qdiff > ag.qdiff_pos_boundary || qdiff < ag.qdiff_neg_boundary) {   // :363
+        // snap the antecedents to the allowed grid (check_possible_states, :146-170)
+        if (threadIdx.x < NANT) {
+            const int k = threadIdx.x;
+            const double r = check_possible_states(sh.q_ant[k], ag.grid_values + (size_t)k * FRIRL_HIP_MAX_GRID, ag.grid_len[k]);
+            sh.rant[k] = r;
+            sh.ve3[k] = observe_ve(u, ve, U, k, r);
+        }
+        __syncthreads();
+        double q3[NANT];
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < NANT; k++) { q3[k] = sh.ve3[k]; same = same && (q3[k] == q1[k]); }
+        QResult rr = rn;                                                    // :370 (same VE point => same sweep result)
+        if (!same) rr = sweep_q<NANT, BLOCK>(base, maxR, R, q3, p, red);
+        if (rr.hit == FRIRL_HIP_NO_HIT) {                                   // :373-377 append and leave
+            if (R >= maxR) return FRIRL_HIP_UPD_FULL;
+            const double rconc = rr.vagc / rr.ws;
+            if (threadIdx.x < NANT) {
+                base[(size_t)threadIdx.x * maxR + R] = q3[threadIdx.x];      // five_add_rule.c:80-81
+                if (rant_e) rant_e[(size_t)threadIdx.x * maxR + R] = sh.rant[threadIdx.x];
+            }
+            if (threadIdx.x == 0) {
+                qcol[R] = rconc + qdiff;
+                *nrules_e = R + 1;
+                *fus_e = 1;
+            }
+            return FRIRL_HIP_UPD_INSERTED;
+        }
+        fus = 0;                                                            // :378
+    }
+
+    // update_rules (:22-143); FIVE_vag_concl_weight(q_ant) sees the distances of the sweep above
+    int rules = R;
+    if (fus) rules--;                                                       // :30-33
+    int status;
+    if (rn.hit != FRIRL_HIP_NO_HIT && (ag.skip_rules == 0 || (ag.skip_rules == 1 && (int)rn.hit < rules))) {
+        if (threadIdx.x == 0) qcol[rn.hit] = qnow + qdiff;                  // :55
+        status = FRIRL_HIP_UPD_EXACT;
+    } else if (ag.skip_rules == 1 && rn.hit != FRIRL_HIP_NO_HIT && (int)rn.hit == rules) {
+        status = FRIRL_HIP_UPD_SKIPPED;                                     // :61-63
+    } else {
+        if (ag.skip_rules == 0) fus = 0;                                    // :70-73
+        const int r_skip = fus ? R - 1 : -1;                                // :76,124-126: the just-inserted rule keeps its Q
+        sweep_update<NANT, BLOCK>(base, maxR, R, q1, p, rn.ws, qnow, qdiff, ag.weight_significant, r_skip);   // K6+K7
+        status = FRIRL_HIP_UPD_SPREAD;
+    }
+    if (threadIdx.x == 0) *fus_e = fus;
+    return status;
+}
+
+template <int NANT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void update_sarsa_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+                                                              double *__restrict__ rb, int32_t *__restrict__ nrules, int maxR,
+                                                              const frirl_hip_agent ag, const frirl_hip_envs ev,
+                                                              const double *__restrict__ q_ant, const double *__restrict__ reward,
+                                                              const double *__restrict__ cur_q_ant, const uint8_t *__restrict__ active)
+{
+    const int e = blockIdx.x;
+    if (active && !active[e]) {
+        if (threadIdx.x == 0 && ev.status) ev.status[e] = FRIRL_HIP_UPD_INACTIVE;
+        return;
+    }
+    __shared__ StepShared sh;
+    __shared__ BlockRed<BLOCK> red;
+    if (threadIdx.x < NANT) {
+        const int k = threadIdx.x;
+        const double a = q_ant[(size_t)e * NANT + k], c = cur_q_ant[(size_t)e * NANT + k];
+        sh.q_ant[k] = a;
+        sh.cur_q_ant[k] = c;
+        sh.ve1[k] = observe_ve(u, ve, U, k, a);
+        sh.ve2[k] = observe_ve(u, ve, U, k, c);
+    }
+    __syncthreads();
+    double *base = rb + (size_t)e * (NANT + 1) * maxR;
+    double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
+    const int st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, reward[e], false, 0.0, ev.fus + e, rant_e, red);
+    if (threadIdx.x == 0 && ev.status) ev.status[e] = st;
+}
+
+// FIVE_add_rule (reference src/five/five_add_rule.c:47-95): one thread per environment.
+__global__ void add_rule_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U, int nant, double *__restrict__ rb,
+                                int32_t *__restrict__ nrules, int maxR, int E, const double *__restrict__ rant,
+                                const double *__restrict__ rconc, const uint8_t *__restrict__ active, double *__restrict__ rant_store,
+                                int32_t *__restrict__ added)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int ok = 0;
+    if (!active || active[e]) {
+        const int R = nrules[e];
+        if (R < maxR) {
+            double *base = rb + (size_t)e * (nant + 1) * maxR;
+            for (int k = 0; k < nant; k++) {
+                const double v = rant[(size_t)e * nant + k];
+                base[(size_t)k * maxR + R] = observe_ve(u, ve, U, k, v);
+                if (rant_store) rant_store[((size_t)e * nant + k) * maxR + R] = v;
+            }
+            base[(size_t)nant * maxR + R] = rconc[e];
+            nrules[e] = R + 1;
+            ok = 1;
+        }
+    }
+    if (added) added[e] = ok;
+}
+
+// do_action + get_reward + quantize_observations: one thread per environment.
+__global__ void env_step_kernel(const frirl_hip_agent ag, int E, int ns, const double *__restrict__ action,
+                                const double *__restrict__ states, double *__restrict__ new_states, double *__restrict__ reward,
+                                int32_t *__restrict__ success, double *__restrict__ q_states)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double s[FRIRL_HIP_MAX_NANT], n[FRIRL_HIP_MAX_NANT], q[FRIRL_HIP_MAX_NANT];
+    for (int i = 0; i < ns; i++) s[i] = states[(size_t)e * ns + i];
+    env_do_action(ag.env_kind, action[e], s, n);
+    double r; int f;
+    env_get_reward(ag.env_kind, n, r, f);
+    env_quantize(ag.env_kind, ns, ag.grid_values, ag.grid_len, ag.grid_div, n, q);
+    for (int i = 0; i < ns; i++) { new_states[(size_t)e * ns + i] = n[i]; q_states[(size_t)e * ns + i] = q[i]; }
+    reward[e] = r;
+    success[e] = f;
+}
+
+// frirl_episode(): start of an episode (reference src/frirl/frirl_episode.c:46-82).
+template <int NANT, int AMAX, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+                                                               const double *__restrict__ rb, const int32_t *__restrict__ nrules,
+                                                               int maxR, const frirl_hip_agent ag, const frirl_hip_envs ev)
+{
+    constexpr int NS = NANT - 1;
+    const int e = blockIdx.x;
+    __shared__ double q_s[NS];
+    __shared__ GbaScratch<AMAX, BLOCK> gs;
+    if (threadIdx.x < NS) {
+        const double v = ag.values_def[threadIdx.x];                          // q_states = states = values_def (:46-48)
+        ev.states[(size_t)e * NS + threadIdx.x] = v;
+        ev.q_ant[(size_t)e * NANT + threadIdx.x] = v;
+        q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, v);
+    }
+    if ((int)threadIdx.x < ag.A) gs.ave[threadIdx.x] = ag.action_ve[threadIdx.x];
+    __syncthreads();
+    double q[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) q[k] = q_s[k];
+    const double *base = rb + (size_t)e * (NANT + 1) * maxR;
+    const int a0 = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);   // :78
+    if (threadIdx.x == 0) {
+        ev.q_ant[(size_t)e * NANT + NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + a0];                 // :82
+        ev.done[e] = 0;
+        ev.ep_steps[e] = 0;
+        ev.ep_reward[e] = 0.0;
+        if (ev.status) ev.status[e] = FRIRL_HIP_UPD_INACTIVE;
+    }
+}
+
+// frirl_episode(): one step of the loop (reference src/frirl/frirl_episode.c:86-185), fused.
+template <int NANT, int AMAX, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+                                                              double *__restrict__ rb, int32_t *__restrict__ nrules, int maxR,
+                                                              const frirl_hip_agent ag, const frirl_hip_envs ev)
+{
+    constexpr int NS = NANT - 1;
+    const int e = blockIdx.x;
+    if (ev.done[e]) {
+        if (threadIdx.x == 0 && ev.status) ev.status[e] = FRIRL_HIP_UPD_INACTIVE;
+        return;
+    }
+    __shared__ StepShared sh;
+    __shared__ BlockRed<BLOCK> red;
+    __shared__ GbaScratch<AMAX, BLOCK> gs;
+    if (threadIdx.x == 0) {
+        double s[FRIRL_HIP_MAX_NANT], q[FRIRL_HIP_MAX_NANT];
+        for (int i = 0; i < NS; i++) s[i] = ev.states[(size_t)e * NS + i];
+        for (int i = 0; i < NANT; i++) sh.q_ant[i] = ev.q_ant[(size_t)e * NANT + i];
+        env_do_action(ag.env_kind, sh.q_ant[NS], s, sh.cur_states);                                   // :97
+        env_get_reward(ag.env_kind, sh.cur_states, sh.reward, sh.success);                            // :106
+        env_quantize(ag.env_kind, NS, ag.grid_values, ag.grid_len, ag.grid_div, sh.cur_states, q);   // :112
+        for (int i = 0; i < NS; i++) sh.cur_q_ant[i] = q[i];
+    }
+    if ((int)threadIdx.x < ag.A) gs.ave[threadIdx.x] = ag.action_ve[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < NANT) sh.ve1[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, sh.q_ant[threadIdx.x]);
+    if (threadIdx.x < NS) sh.ve2[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, sh.cur_q_ant[threadIdx.x]);
+    __syncthreads();
+    double q[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) q[k] = sh.ve2[k];
+    double *base = rb + (size_t)e * (NANT + 1) * maxR;
+    const int ap = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);    // :148
+    const double qp = gs.actconc[ap];          // == FIVE_vag_concl(cur_q_ant) of frirl_update_sarsa.c:356
+    if (threadIdx.x == 0) {
+        sh.cur_q_ant[NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + ap];                      // :151
+        sh.ve2[NS] = gs.ave[ap];
+    }
+    __syncthreads();
+    double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
+    const int st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red);  // :159
+    if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
+    if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.cur_q_ant[threadIdx.x];    // :166-168
+    if (threadIdx.x == 0) {
+        const int steps = ev.ep_steps[e] + 1;                                                         // :174
+        ev.ep_steps[e] = steps;
+        ev.ep_reward[e] = ev.ep_reward[e] + sh.reward;                                                // :107
+        if (sh.success == 1 || steps >= ag.max_steps) ev.done[e] = 1;                                 // :183, :86
+        if (ev.status) ev.status[e] = st;
+    }
+}
+
+}  // namespace frirl
+
+using namespace frirl_host;
+
+static int check_agent(const frirl_hip_tables *t, const frirl_hip_agent *a, const char *who)
+{
+    if (!a || !a->grid_values) { set_error("%s: NULL agent / grid_values", who); return FRIRL_HIP_EINVAL; }
+    for (int k = 0; k < t->nant; k++)
+        if (a->grid_len[k] < 1 || a->grid_len[k] > FRIRL_HIP_MAX_GRID) { set_error("%s: grid_len[%d]=%d outside 1..%d", who, k, a->grid_len[k], FRIRL_HIP_MAX_GRID); return FRIRL_HIP_EINVAL; }
+    return FRIRL_HIP_OK;
+}
+
+extern "C" int five_hip_add_rule(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const double *rant, const double *rconc,
+                                 const uint8_t *active, double *rant_store, int32_t *added, void *stream)
+{
+    int rc = check_rulebases(t, b);
+    if (rc) return rc;
+    if (!rant || !rconc) { set_error("five_hip_add_rule: NULL rant/rconc"); return FRIRL_HIP_EINVAL; }
+    if ((rc = check_device())) return rc;
+    hipLaunchKernelGGL(frirl::add_rule_kernel, dim3((b->E + 255) / 256), dim3(256), 0, as_stream(stream), t->u, t->ve, t->U, t->nant, b->rb,
+                       b->nrules, b->maxR, b->E, rant, rconc, active, rant_store, added);
+    return check_launch("five_hip_add_rule");
+}
+
+#define FRIRL_Q_NANT_CASES(M) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+
+extern "C" int frirl_hip_update_sarsa(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                                      const frirl_hip_envs *envs, const double *q_ant, const double *reward, const double *cur_q_ant,
+                                      const uint8_t *active, void *stream)
+{
+    int rc = check_rulebases(t, b);
+    if (rc) return rc;
+    if ((rc = check_agent(t, agent, "frirl_hip_update_sarsa"))) return rc;
+    if (!envs || !envs->fus || !q_ant || !reward || !cur_q_ant) { set_error("frirl_hip_update_sarsa: NULL argument"); return FRIRL_HIP_EINVAL; }
+    if ((rc = check_device())) return rc;
+    hipStream_t s = as_stream(stream);
+    const bool big = b->E < 256;
+    switch (t->nant) {
+#define M(N)                                                                                                                              \
+    case N:                                                                                                                               \
+        if (big) hipLaunchKernelGGL((frirl::update_sarsa_kernel<N, 1024>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, \
+                                    b->maxR, *agent, *envs, q_ant, reward, cur_q_ant, active);                                            \
+        else hipLaunchKernelGGL((frirl::update_sarsa_kernel<N, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,     \
+                                b->maxR, *agent, *envs, q_ant, reward, cur_q_ant, active);                                                \
+        break;
+        FRIRL_Q_NANT_CASES(M)
+#undef M
+        default: set_error("frirl_hip_update_sarsa: nant=%d outside 2..9", t->nant); return FRIRL_HIP_EINVAL;
+    }
+    return check_launch("frirl_hip_update_sarsa");
+}
+
+extern "C" int frirl_hip_env_step(const frirl_hip_agent *agent, int32_t E, int32_t nstates, const double *action, const double *states,
+                                  double *new_states, double *reward, int32_t *success, double *q_states, void *stream)
+{
+    if (!agent || !agent->grid_values || !action || !states || !new_states || !reward || !success || !q_states) { set_error("frirl_hip_env_step: NULL argument"); return FRIRL_HIP_EINVAL; }
+    if (E < 1 || nstates < 1 || nstates >= FRIRL_HIP_MAX_NANT) { set_error("frirl_hip_env_step: bad E/nstates"); return FRIRL_HIP_EINVAL; }
+    const int need = agent->env_kind == FRIRL_HIP_ENV_MOUNTAINCAR ? 2 : 4;
+    if (agent->env_kind < 0 || agent->env_kind > 2 || nstates != need) { set_error("frirl_hip_env_step: env_kind %d needs %d state dims", agent->env_kind, need); return FRIRL_HIP_EINVAL; }
+    int rc = check_device();
+    if (rc) return rc;
+    hipLaunchKernelGGL(frirl::env_step_kernel, dim3((E + 255) / 256), dim3(256), 0, as_stream(stream), *agent, E, nstates, action, states,
+                       new_states, reward, success, q_states);
+    return check_launch("frirl_hip_env_step");
+}
+
+template <int N, bool BEGIN>
+static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                           hipStream_t s)
+{
+#define L(AMAX)                                                                                                                        \
+    do {                                                                                                                               \
+        if (BEGIN) hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, \
+                                      b->nrules, b->maxR, *ag, *ev);                                                                   \
+        else hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb,       \
+                                b->nrules, b->maxR, *ag, *ev);                                                                         \
+    } while (0)
+    if (ag->A <= 4) L(4);
+    else if (ag->A <= 8) L(8);
+    else if (ag->A <= 16) L(16);
+    else L(32);
+#undef L
+}
+
+static int check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                         const frirl_hip_envs *envs, const char *who)
+{
+    int rc = check_rulebases(t, b);
+    if (rc) return rc;
+    if ((rc = check_agent(t, agent, who))) return rc;
+    if (!agent->action_ve || agent->A < 1 || agent->A > FRIRL_HIP_MAX_ACTIONS) { set_error("%s: bad action table", who); return FRIRL_HIP_EINVAL; }
+    if (!envs || !envs->states || !envs->q_ant || !envs->fus || !envs->done || !envs->ep_steps || !envs->ep_reward) { set_error("%s: NULL env state", who); return FRIRL_HIP_EINVAL; }
+    const int need = agent->env_kind == FRIRL_HIP_ENV_MOUNTAINCAR ? 3 : 5;
+    if (agent->env_kind < 0 || agent->env_kind > 2 || t->nant != need) { set_error("%s: env_kind %d needs nant=%d", who, agent->env_kind, need); return FRIRL_HIP_EINVAL; }
+    return check_device();
+}
+
+extern "C" int frirl_hip_episode_begin(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                                       const frirl_hip_envs *envs, void *stream)
+{
+    int rc = check_episode(t, b, agent, envs, "frirl_hip_episode_begin");
+    if (rc) return rc;
+    if (t->nant == 3) launch_episode<3, true>(t, b, agent, envs, as_stream(stream));
+    else launch_episode<5, true>(t, b, agent, envs, as_stream(stream));
+    return check_launch("frirl_hip_episode_begin");
+}
+
+extern "C" int frirl_hip_episode_step(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                                      const frirl_hip_envs *envs, void *stream)
+{
+    int rc = check_episode(t, b, agent, envs, "frirl_hip_episode_step");
+    if (rc) return rc;
+    if (t->nant == 3) launch_episode<3, false>(t, b, agent, envs, as_stream(stream));
+    else launch_episode<5, false>(t, b, agent, envs, as_stream(stream));
+    return check_launch("frirl_hip_episode_step");
+}

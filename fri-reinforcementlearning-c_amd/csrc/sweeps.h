@@ -1,0 +1,248 @@
+// sweeps.h -- workgroup-level sweeps over ONE rule base (device functions).
+//
+// One workgroup owns one environment's rule base for the duration of a sweep (the reference's
+// model: one private FIVERB per agent, src/frirl/frirl_agent.c:229-238), so no inter-workgroup
+// communication and no float atomics are needed.  Every lane streams 16 B (two rules) per SoA
+// column per iteration; partial sums are lane-strided and combined by a fixed butterfly + wave
+// order (deterministic).  These sweeps are shared by the thin per-function kernels
+// (fiveq.hip) and by the fused SARSA / episode-step kernels (sarsa.hip).
+#pragma once
+
+#include "device_common.h"
+
+namespace frirl {
+
+// b^p by repeated multiplication -- reference src/inl/fast_pow.inl:17-31, in plain double (the
+// reference keeps the running product in x87 extended precision; see include/frirl_hip.h).
+__device__ __forceinline__ double pow_int(double b, int p)
+{
+    double r = b;
+    for (int i = 1; i < p; i++) r = r * b;
+    return r;
+}
+
+template <int BLOCK>
+struct BlockRed {
+    static constexpr int WAVES = BLOCK / FRIRL_WAVE;
+    double d[WAVES];
+    unsigned u[WAVES];
+};
+
+template <int BLOCK>
+__device__ __forceinline__ unsigned blk_min(unsigned v, BlockRed<BLOCK> &s)
+{
+    v = wave_min_u32(v);
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+    if (lane == 0) s.u[wave] = v;
+    __syncthreads();
+    unsigned m = s.u[0];
+#pragma unroll
+    for (int w = 1; w < BlockRed<BLOCK>::WAVES; w++) m = (s.u[w] < m) ? s.u[w] : m;
+    __syncthreads();
+    return m;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ double blk_sum(double v, BlockRed<BLOCK> &s)
+{
+    v = wave_sum_f64(v);
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+    if (lane == 0) s.d[wave] = v;
+    __syncthreads();
+    double t = s.d[0];
+#pragma unroll
+    for (int w = 1; w < BlockRed<BLOCK>::WAVES; w++) t = t + s.d[w];
+    __syncthreads();
+    return t;
+}
+
+// Squared VE distance of two adjacent rules (r, r+1) to the observation q over dims [0, NDIM):
+// dimension-ordered, separate multiply and add (five_rule_distance.c:88-90,171-208).
+template <int NDIM>
+__device__ __forceinline__ void sq_dist2(const double *__restrict__ base, int maxR, int r, const double (&q)[NDIM], double &a0, double &a1)
+{
+    double2 v[NDIM];
+#pragma unroll
+    for (int k = 0; k < NDIM; k++) v[k] = *reinterpret_cast<const double2 *>(base + (size_t)k * maxR + r);
+    double d0 = q[0] - v[0].x, d1 = q[0] - v[0].y;
+    a0 = d0 * d0;
+    a1 = d1 * d1;
+#pragma unroll
+    for (int k = 1; k < NDIM; k++) {
+        d0 = q[k] - v[k].x;
+        d1 = q[k] - v[k].y;
+        const double s0 = d0 * d0, s1 = d1 * d1;
+        a0 = a0 + s0;
+        a1 = a1 + s1;
+    }
+}
+
+struct QResult {
+    unsigned hit;   // lowest rule index with distance exactly 0, or FRIRL_HIP_NO_HIT
+    double vagc;    // sum wi * Q   (valid when hit == NO_HIT)
+    double ws;      // sum wi
+};
+
+// FIVE_vag_concl's sweep (reference src/five/FIVEVagConcl.c:64-351 live path): distances, first
+// exact hit, Shepard sums wi = 1/d^p, vagc = sum wi*Q, ws = sum wi (:224-235).  All threads return
+// the same QResult.
+template <int NANT, int BLOCK>
+__device__ QResult sweep_q(const double *__restrict__ base, int maxR, int R, const double (&q)[NANT], int p, BlockRed<BLOCK> &red)
+{
+    unsigned best = FRIRL_HIP_NO_HIT;
+    double sv = 0.0, sw = 0.0;
+    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
+    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
+        double a0, a1;
+        sq_dist2<NANT>(base, maxR, r, q, a0, a1);
+        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        const double d0 = __dsqrt_rn(a0), d1 = __dsqrt_rn(a1);
+        if (d0 == 0.0) best = min(best, (unsigned)r);
+        else {
+            const double wi = 1.0 / pow_int(d0, p);
+            const double t = wi * c.x;
+            sv = sv + t;
+            sw = sw + wi;
+        }
+        if (r + 1 < R) {
+            if (d1 == 0.0) best = min(best, (unsigned)(r + 1));
+            else {
+                const double wi = 1.0 / pow_int(d1, p);
+                const double t = wi * c.y;
+                sv = sv + t;
+                sw = sw + wi;
+            }
+        }
+    }
+    QResult res;
+    res.hit = blk_min<BLOCK>(best, red);
+    res.vagc = blk_sum<BLOCK>(sv, red);
+    res.ws = blk_sum<BLOCK>(sw, red);
+    return res;
+}
+
+// FIVE_vag_concl_weight's second pass (reference src/five/FIVEVagConclWeight.c:125-166, K6):
+// weights[r] = (1/d_r^p) / ws for r < R.  Distances are recomputed (8*nant B/rule re-read) instead
+// of spilling wi[] to HBM and reading it back (16 B/rule).
+template <int NANT, int BLOCK>
+__device__ void sweep_weights(const double *__restrict__ base, int maxR, int R, const double (&q)[NANT], int p, double ws,
+                              double *__restrict__ weights)
+{
+    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
+        double a0, a1;
+        sq_dist2<NANT>(base, maxR, r, q, a0, a1);
+        const double w0 = (1.0 / pow_int(__dsqrt_rn(a0), p)) / ws;
+        const double w1 = (1.0 / pow_int(__dsqrt_rn(a1), p)) / ws;
+        if (r + 1 < R) {
+            double2 w; w.x = w0; w.y = w1;
+            *reinterpret_cast<double2 *>(weights + r) = w;
+        } else weights[r] = w0;
+    }
+}
+
+// update_rules' masked write-back (reference src/frirl/frirl_update_sarsa.c:89-120, K7):
+// rconc[r] = qnow + qdiff * w_r where w_r = wi_r / ws > threshold (strict, ordered compare).
+// `r_skip` (or -1) is left untouched: the just-inserted last rule under skip_rules (:31-33,124-126).
+template <int NANT, int BLOCK>
+__device__ void sweep_update(double *__restrict__ base, int maxR, int R, const double (&q)[NANT], int p, double ws, double qnow,
+                             double qdiff, double threshold, int r_skip)
+{
+    double *__restrict__ qcol = base + (size_t)NANT * maxR;
+    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
+        double a0, a1;
+        sq_dist2<NANT>(base, maxR, r, q, a0, a1);
+        const double w0 = (1.0 / pow_int(__dsqrt_rn(a0), p)) / ws;
+        const double w1 = (1.0 / pow_int(__dsqrt_rn(a1), p)) / ws;
+        if (w0 > threshold && r != r_skip) { const double t = qdiff * w0; qcol[r] = qnow + t; }
+        if (r + 1 < R && w1 > threshold && r + 1 != r_skip) { const double t = qdiff * w1; qcol[r + 1] = qnow + t; }
+    }
+}
+
+// frirl_get_best_action's sweep (reference src/frirl/frirl_get_best_action.c:31-341): the state
+// part of the squared distance is computed once per rule (K3/K4 :58-155) and shared by all A
+// actions; per action a: d = sqrt((vevalues[a] - ract_veval[r])^2 + statesum) (K5 :252-275), then
+// FIVEVagConcl_FRIRL_BestAct (first exact hit, else Shepard; FIVEVagConcl_FRIRL_BestAct.c:89-93,
+// 212-217,265).  A accumulator pairs live in registers (AMAX is the compile-time bucket).
+// Results: actconc[a] for a < A in `actconc_s` (LDS, >= AMAX doubles); returns the first maximum
+// (src/inl/max.inl:16-28).  `scratch` needs WAVES*AMAX doubles x2 and WAVES*AMAX unsigned.
+template <int AMAX, int BLOCK>
+struct GbaScratch {
+    static constexpr int WAVES = BLOCK / FRIRL_WAVE;
+    double v[WAVES][AMAX];
+    double w[WAVES][AMAX];
+    unsigned h[WAVES][AMAX];
+    double actconc[AMAX];
+    double ave[AMAX];
+    int best;
+};
+
+template <int NANT, int AMAX, int BLOCK>
+__device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1], int p, int A,
+                         GbaScratch<AMAX, BLOCK> &s)
+{
+    constexpr int NS = NANT - 1;
+    double sv[AMAX], sw[AMAX], av[AMAX];
+    unsigned sh[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; av[a] = (a < A) ? s.ave[a] : 0.0; }
+    const double *__restrict__ acol = base + (size_t)NS * maxR;
+    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
+    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
+        double s0 = 0.0, s1 = 0.0;
+        if (NS > 0) sq_dist2<(NS > 0 ? NS : 1)>(base, maxR, r, qs, s0, s1);
+        const double2 va = *reinterpret_cast<const double2 *>(acol + r);
+        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        const bool second = (r + 1 < R);
+#pragma unroll
+        for (int a = 0; a < AMAX; a++) {
+            if (a < A) {
+                const double e0 = av[a] - va.x, e1 = av[a] - va.y;
+                const double f0 = e0 * e0, f1 = e1 * e1;
+                const double d0 = __dsqrt_rn(f0 + s0), d1 = __dsqrt_rn(f1 + s1);
+                if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
+                else {
+                    const double wi = 1.0 / pow_int(d0, p);
+                    const double t = wi * c.x;
+                    sv[a] = sv[a] + t;
+                    sw[a] = sw[a] + wi;
+                }
+                if (second) {
+                    if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
+                    else {
+                        const double wi = 1.0 / pow_int(d1, p);
+                        const double t = wi * c.y;
+                        sv[a] = sv[a] + t;
+                        sw[a] = sw[a] + wi;
+                    }
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+        if (a < A) {
+            const double tv = wave_sum_f64(sv[a]), tw = wave_sum_f64(sw[a]);
+            const unsigned th = wave_min_u32(sh[a]);
+            if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; s.h[wave][a] = th; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < A) {
+        const int a = threadIdx.x;
+        double tv = s.v[0][a], tw = s.w[0][a];
+        unsigned th = s.h[0][a];
+        for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; th = min(th, s.h[w][a]); }
+        s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int a = 1; a < A; a++) if (s.actconc[best] < s.actconc[a]) best = a;   // strict <: first maximum wins
+        s.best = best;
+    }
+    __syncthreads();
+    return s.best;
+}
+
+}  // namespace frirl

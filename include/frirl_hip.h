@@ -45,7 +45,20 @@ extern "C" {
 
 #define FRIRL_HIP_MAX_NANT     16   /* reference: FIVE_MAX_NUM_OF_UNIVERSES 8 (src/five/FIVE.h:19) */
 #define FRIRL_HIP_MAX_ACTIONS  32
+#define FRIRL_HIP_MAX_GRID     64   /* possible rule places per antecedent */
 #define FRIRL_HIP_NO_HIT       0xFFFFFFFFu
+
+#define FRIRL_HIP_ENV_MOUNTAINCAR 0   /* reference examples/mountaincar/mountaincar.c */
+#define FRIRL_HIP_ENV_CARTPOLE    1   /* reference examples/cartpole/cartpole.c       */
+#define FRIRL_HIP_ENV_ACROBOT     2   /* reference examples/acrobot/acrobot.c         */
+
+/* outcome of one SARSA update per environment (frirl_hip_envs.status) */
+#define FRIRL_HIP_UPD_INACTIVE   0    /* environment masked out / episode already ended              */
+#define FRIRL_HIP_UPD_EXACT      1    /* exact hit: rconc[hit] = qnow + qdiff   (frirl_update_sarsa.c:55)  */
+#define FRIRL_HIP_UPD_SPREAD     2    /* weighted spread over rules with w > threshold (K7, :89-120)       */
+#define FRIRL_HIP_UPD_INSERTED   3    /* new rule appended (FIVE_add_rule, :373-377)                       */
+#define FRIRL_HIP_UPD_SKIPPED    4    /* hit on the just-inserted rule under skip_rules (:61-63)           */
+#define FRIRL_HIP_UPD_FULL       5    /* rule base at capacity: append refused, nothing changed            */
 
 #define FRIRL_HIP_OK        0
 #define FRIRL_HIP_ENODEV   -1   /* no gfx950 device / HIP runtime unusable */
@@ -87,6 +100,101 @@ int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, in
  */
 int five_hip_rule_distance(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const double *x,
                            double *ruledists, uint32_t *hit, void *stream);
+
+/* ---- FIVE_vag_concl (reference src/five/FIVEVagConcl.c:64-351, default-flag live path) ------
+ * Q value of one observation per rule base: the consequent of the first exact-hit rule, else the
+ * Shepard interpolation sum_r wi*Q_r / sum_r wi with wi = 1 / d_r^p (:224-235,302).  p <= 0 selects
+ * the reference default p = nant (FIVEInit.c:89-93).
+ *   x [dev][E][nant], conc [dev][E], hit [dev][E] (uint32, FRIRL_HIP_NO_HIT when interpolated) */
+int five_hip_vag_concl(const frirl_hip_tables *t, const frirl_hip_rulebases *b, int p, const double *x,
+                       double *conc, uint32_t *hit, void *stream);
+
+/* ---- FIVE_vag_concl_weight (reference src/five/FIVEVagConclWeight.c:52-188) ------------------
+ * Normalised Shepard weights weights[e][r] = wi_r / sum wi for r < nrules[e]; when the observation
+ * hits a rule exactly, hit[e] is that rule and weights[e][*] is NOT written (as the reference).
+ *   weights [dev][E][maxR] (16-byte aligned) */
+int five_hip_vag_concl_weight(const frirl_hip_tables *t, const frirl_hip_rulebases *b, int p, const double *x,
+                              double *weights, uint32_t *hit, void *stream);
+
+/* ---- frirl_get_best_action (reference src/frirl/frirl_get_best_action.c:31-341) --------------
+ * Greedy action per environment: actconc[e][a] = Q(states[e], action a) for the A discrete actions
+ * (FIVEVagConcl_FRIRL_BestAct, src/five/FIVEVagConcl_FRIRL_BestAct.c:56-299), best[e] = first
+ * maximum (src/inl/max.inl:16-28).  action_ve[a] is the VE value of action a
+ * (frirl_desc.possible_actions->vevalues, frirl_init.c:156-158).  nant must be 2..9, A <= 32.
+ *   states [dev][E][nant-1], action_ve [dev][A], actconc [dev][E][A], best [dev][E] int32 */
+int frirl_hip_get_best_action(const frirl_hip_tables *t, const frirl_hip_rulebases *b, int p, const double *states,
+                              const double *action_ve, int A, double *actconc, int32_t *best, void *stream);
+
+/* Agent hyper-parameters and grids (reference struct frirl_desc, src/frirl/frirl_types.h:62-169;
+ * defaults src/frirl/frirl_types_def.h:22-77).  Passed by pointer, copied by value into the launch. */
+typedef struct frirl_hip_agent {
+    double alpha, gamma;                       /* frirl_desc.alpha / .gamma                                */
+    double qdiff_pos_boundary;                 /* insert a rule when qdiff > this ...                      */
+    double qdiff_neg_boundary;                 /* ... or qdiff < this (frirl_update_sarsa.c:363)           */
+    double weight_significant;                 /* rule_weight_considered_significant_for_update (0.05)     */
+    int32_t skip_rules;                        /* frirl_desc.skip_rules (MATLAB compatibility, 1 in demos) */
+    int32_t p;                                 /* Shepard power, <= 0 -> nant (FIVEInit.c:89-93)           */
+    int32_t A;                                 /* number of discrete actions                               */
+    int32_t env_kind;                          /* FRIRL_HIP_ENV_*                                          */
+    int32_t max_steps;                         /* frirl_desc.max_steps                                     */
+    int32_t reserved;
+    int32_t grid_len[FRIRL_HIP_MAX_NANT];      /* possible rule places per antecedent (states.., action)   */
+    double grid_div[FRIRL_HIP_MAX_NANT];       /* statedims[i].values_div (generic quantiser)              */
+    double values_def[FRIRL_HIP_MAX_NANT];     /* statedims[i].values_def: episode start state             */
+    const double *grid_values;                 /* [dev] [nant][FRIRL_HIP_MAX_GRID]; row nant-1 = action values */
+    const double *action_ve;                   /* [dev] [A] possible_actions->vevalues (frirl_init.c:156-158) */
+} frirl_hip_agent;
+
+/* Per-environment episode state (reference: fields of frirl_desc + frirl_reward_desc that
+ * frirl_episode() carries from step to step, src/frirl/frirl_episode.c:28-194). */
+typedef struct frirl_hip_envs {
+    double *states;          /* [dev] [E][nant-1] continuous state (fep_ant)                              */
+    double *q_ant;           /* [dev] [E][nant]   quantised state + action of the pending update (fep_q_ant) */
+    int32_t *fus;            /* [dev] [E] sticky fus_is_rule_inserted (frirl_update_sarsa.c:374,378,73)   */
+    int32_t *done;           /* [dev] [E] 1 once the episode ended (success or max_steps)                 */
+    int32_t *ep_steps;       /* [dev] [E] reward.ep_total_steps                                           */
+    double *ep_reward;       /* [dev] [E] reward.ep_total_value                                           */
+    double *rant;            /* [dev] [E][nant][maxR] raw antecedents of the rules (FIVERB.rant, SoA), or NULL */
+    int32_t *status;         /* [dev] [E] FRIRL_HIP_UPD_* of the last update, or NULL                     */
+} frirl_hip_envs;
+
+/* ---- FIVE_add_rule (reference src/five/five_add_rule.c:47-95) ---------------------------------
+ * Appends one rule per environment where active[e] != 0 (active == NULL: all): rb[e][k][R] =
+ * ve[k][snap(rant[e][k])], rb[e][nant][R] = rconc[e], nrules[e]++.  Unlike the reference the
+ * capacity is checked: a full rule base is left unchanged and added[e] = 0.
+ *   rant [dev][E][nant], rconc [dev][E], active [dev][E] uint8 or NULL, rant_store = envs-style
+ *   [dev][E][nant][maxR] or NULL, added [dev][E] int32 or NULL */
+int five_hip_add_rule(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const double *rant, const double *rconc,
+                      const uint8_t *active, double *rant_store, int32_t *added, void *stream);
+
+/* ---- frirl_update_sarsa (reference src/frirl/frirl_update_sarsa.c:348-385 + update_rules :22-143,
+ *      check_possible_states :146-170, CHECK_STATES = 1) ---------------------------------------------
+ * One TD step per environment: qdiff = alpha*(reward + gamma*Q(s',a') - Q(s,a)); either a rule is
+ * appended at the grid-snapped antecedents or qdiff is written to the exact-hit rule / spread over
+ * the rules whose normalised Shepard weight exceeds the threshold.  envs->fus is read and updated;
+ * envs->rant / envs->status may be NULL.  active == NULL: every environment.
+ *   q_ant [dev][E][nant], reward [dev][E], cur_q_ant [dev][E][nant] */
+int frirl_hip_update_sarsa(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                           const frirl_hip_envs *envs, const double *q_ant, const double *reward, const double *cur_q_ant,
+                           const uint8_t *active, void *stream);
+
+/* ---- env step: do_action + get_reward + quantize_observations of the three demo environments
+ *      (reference examples/<env>/<env>.c; FMA-free portable sin/cos) -------------
+ *   action [dev][E] action VALUES, states [dev][E][ns] -> new_states, reward [dev][E],
+ *   success [dev][E] int32, q_states [dev][E][ns] quantised new states */
+int frirl_hip_env_step(const frirl_hip_agent *agent, int32_t E, int32_t nstates, const double *action, const double *states,
+                       double *new_states, double *reward, int32_t *success, double *q_states, void *stream);
+
+/* ---- frirl_episode (reference src/frirl/frirl_episode.c:28-194), batched -----------------------
+ * frirl_hip_episode_begin: states = q_states = values_def, first action chosen greedily on the
+ * un-quantised default state (:46-48,78), counters cleared, done = 0.
+ * frirl_hip_episode_step: ONE environment step for every environment that is not done:
+ * do_action, get_reward, quantise, greedy action for the new state (one sweep giving Q(s',a') for
+ * all a'), SARSA update, bookkeeping (:86-185).  Fused: one workgroup owns one environment. */
+int frirl_hip_episode_begin(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                            const frirl_hip_envs *envs, void *stream);
+int frirl_hip_episode_step(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                           const frirl_hip_envs *envs, void *stream);
 
 #ifdef __cplusplus
 }

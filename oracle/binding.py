@@ -32,6 +32,11 @@ class OrcDim(C.Structure):
                 ("values_steep", C.c_double), ("values_def", C.c_double), ("universe_div", C.c_double)]
 
 
+class OrcAgent(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("gamma", C.c_double), ("qdiff_pos_boundary", C.c_double), ("qdiff_neg_boundary", C.c_double),
+                ("weight_significant", C.c_double), ("skip_rules", C.c_int), ("grid", c_double_p * MAX_NANT), ("grid_len", C.c_int * MAX_NANT)]
+
+
 def build(force=False):
     src = [os.path.join(HERE, "frirl_oracle.c"), os.path.join(HERE, "frirl_oracle.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
@@ -63,6 +68,9 @@ def lib():
         "orc_vag_concl": (C.c_uint, [F, c_double_p, c_double_p]),
         "orc_vag_concl_weight": (C.c_uint, [F, c_double_p, c_double_p]),
         "orc_bestact": (d, [F, c_double_p]),
+        "orc_five_best_action": (C.c_uint, [F, c_double_p, c_double_p, i, c_double_p]),
+        "orc_five_update_sarsa": (None, [F, C.POINTER(OrcAgent), c_double_p, c_double_p, d, c_double_p]),
+        "orc_frirl_agent": (None, [vp, C.POINTER(OrcAgent)]),
         "orc_frirl_new": (vp, [i, i, i]),
         "orc_frirl_delete": (None, [vp]),
         "orc_frirl_frb": (F, [vp]),
@@ -81,6 +89,7 @@ def lib():
         "orc_frirl_ep_steps": (i, [vp]),
         "orc_frirl_ep_reward": (d, [vp]),
         "orc_frirl_hparams": (None, [vp, c_double_p]),
+        "orc_frirl_set_trace": (None, [vp, vp]),
         "orc_get_best_action": (C.c_uint, [vp, c_double_p]),
         "orc_check_possible_states": (d, [d, c_double_p, i]),
         "orc_update_sarsa": (None, [vp, c_double_p, d, c_double_p]),
@@ -236,6 +245,21 @@ class Five:
         h = lib().orc_vag_concl_weight(self.h, dp(x), self.c.weights)
         return -1 if h == 0xFFFFFFFF else int(h)
 
+    def best_action(self, states, action_ve):
+        st = np.ascontiguousarray(states, dtype=np.float64)
+        av = np.ascontiguousarray(action_ve, dtype=np.float64)
+        out = np.zeros(len(av))
+        b = lib().orc_five_best_action(self.h, dp(st), dp(av), len(av), dp(out))
+        return int(b), out
+
+    def update_sarsa(self, agent, fus, q_ant, reward, cur_q_ant):
+        """agent: Agent; fus: float flag in; returns the flag after the update."""
+        a = np.ascontiguousarray(q_ant, dtype=np.float64)
+        b = np.ascontiguousarray(cur_q_ant, dtype=np.float64)
+        f = C.c_double(fus)
+        lib().orc_five_update_sarsa(self.h, C.byref(agent.c), C.byref(f), dp(a), float(reward), dp(b))
+        return f.value
+
     def device_layout(self, maxR=None):
         """rb[nant+1][maxR] float64: antecedent VE values per dimension, then consequents."""
         maxR = maxR or self.maxR
@@ -244,6 +268,22 @@ class Five:
         rb[: self.nant, :R] = self.veval[:, :R]
         rb[self.nant, :R] = self.rconc[:R]
         return rb
+
+
+class Agent:
+    """orc_agent: SARSA hyper-parameters + the grid of possible rule places per antecedent."""
+
+    def __init__(self, alpha, gamma, qdiff_pos, qdiff_neg, weight_thr, skip_rules, grids):
+        self.grids = [np.ascontiguousarray(g, dtype=np.float64) for g in grids]     # keep alive
+        self.c = OrcAgent()
+        self.c.alpha, self.c.gamma = alpha, gamma
+        self.c.qdiff_pos_boundary, self.c.qdiff_neg_boundary = qdiff_pos, qdiff_neg
+        self.c.weight_significant, self.c.skip_rules = weight_thr, skip_rules
+        for k, g in enumerate(self.grids):
+            self.c.grid[k] = dp(g)
+            self.c.grid_len[k] = len(g)
+        self.alpha, self.gamma, self.qdiff_pos, self.qdiff_neg = alpha, gamma, qdiff_pos, qdiff_neg
+        self.weight_thr, self.skip_rules = weight_thr, skip_rules
 
 
 class Frirl:
@@ -282,6 +322,11 @@ class Frirl:
         lib().orc_frirl_hparams(self.h, dp(out))
         return dict(alpha=out[0], gamma=out[1], qdiff_pos=out[2], qdiff_neg=out[3], weight_thr=out[4],
                     skip_rules=int(out[5]), reward_good_above=out[6], qdiff_final_tolerance=out[7])
+
+    def agent(self):
+        hp = self.hparams
+        return Agent(hp["alpha"], hp["gamma"], hp["qdiff_pos"], hp["qdiff_neg"], hp["weight_thr"], hp["skip_rules"],
+                     [self.dim(k)["values"] for k in range(self.nant)])
 
     @property
     def fus(self):

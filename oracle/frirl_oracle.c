@@ -670,12 +670,13 @@ void orc_frirl_deinit(orc_frirl *fr)
 /* src/frirl/frirl_get_best_action.c:31-341.  K3/K4 (:58-155): state-only squared distances
  * summed in dimension order; K5 (:252-275) per action: sqrt((vevalues[a]-ract_veval[r])^2 +
  * statedistsum[r]); conclusion per action by FIVEVagConcl_FRIRL_BestAct (:325); first maximum
- * wins (src/inl/max.inl:16-28). */
-unsigned orc_get_best_action(orc_frirl *fr, const double *states)
+ * wins (src/inl/max.inl:16-28).  Bare form: any rule base + the per-action VE values. */
+unsigned orc_five_best_action(orc_five *f, const double *states, const double *action_ve, int A, double *actconc)
 {
-    orc_five *f = fr->frb;
-    const int n = f->nant, ns = n - 1, U = f->U, R = f->R, A = fr->actiondim.values_len;
+    const int n = f->nant, ns = n - 1, U = f->U, R = f->R;
     double q[ORC_MAX_NANT];
+    double *statedistsum = f->wi;          /* scratch: wi[] is only live inside orc_vag_concl_weight */
+    double *ruledist = f->ruledists;
     for (int k = 0; k < ns; k++) q[k] = f->ve[k * U + orc_snap(f->u + k * U, U, states[k], f->udivs[k])];
     for (int r = 0; r < R; r++) {
         double d0 = q[0] - f->veval[r];
@@ -685,20 +686,25 @@ unsigned orc_get_best_action(orc_frirl *fr, const double *states)
             double sq = d * d;
             acc = acc + sq;
         }
-        fr->statedistsum[r] = acc;
+        statedistsum[r] = acc;
     }
     const double *av = f->veval + (size_t)ns * f->maxR;
     for (int a = 0; a < A; a++) {
         for (int r = 0; r < R; r++) {
-            double da = fr->action_vevalues[a] - av[r];
+            double da = action_ve[a] - av[r];
             double sq = da * da;
-            fr->ruledist[r] = sqrt(sq + fr->statedistsum[r]);
+            ruledist[r] = sqrt(sq + statedistsum[r]);
         }
-        fr->actconc[a] = orc_bestact(f, fr->ruledist);
+        actconc[a] = orc_bestact(f, ruledist);
     }
     int best = 0;
-    for (int a = 1; a < A; a++) if (fr->actconc[best] < fr->actconc[a]) best = a;
+    for (int a = 1; a < A; a++) if (actconc[best] < actconc[a]) best = a;
     return (unsigned)best;
+}
+
+unsigned orc_get_best_action(orc_frirl *fr, const double *states)
+{
+    return orc_five_best_action(fr->frb, states, fr->action_vevalues, fr->actiondim.values_len, fr->actconc);
 }
 
 /* src/frirl/frirl_e_greedy_selection.c:21-37.  Every shipped demo keeps no_random = 1, so the
@@ -723,51 +729,66 @@ double orc_check_possible_states(double obs, const double *v, int n)
 }
 
 /* src/frirl/frirl_update_sarsa.c:22-143 */
-static void orc_update_rules(orc_frirl *fr, const double *values, double qnow, double qdiff)
+static void orc_update_rules(orc_five *f, const orc_agent *ag, double *fus, const double *values, double qnow, double qdiff)
 {
-    orc_five *f = fr->frb;
     int rules = f->R;
-    if (fr->fus_is_rule_inserted) rules--;                                        /* :30-33 */
+    if (*fus) rules--;                                                            /* :30-33 */
     unsigned hit = orc_vag_concl_weight(f, values, f->weights);                   /* :40 */
-    if (hit != ~0u && (fr->skip_rules == 0 || (fr->skip_rules == 1 && hit < (unsigned)rules))) {
+    if (hit != ~0u && (ag->skip_rules == 0 || (ag->skip_rules == 1 && hit < (unsigned)rules))) {
         f->rconc[hit] = qnow + qdiff;                                             /* :55 */
         return;
-    } else if (fr->skip_rules == 1 && hit == (unsigned)rules) {
+    } else if (ag->skip_rules == 1 && hit == (unsigned)rules) {
         return;                                                                   /* :61-63 */
     }
     double save = 0;
-    if (fr->skip_rules == 0) fr->fus_is_rule_inserted = 0;                        /* :70-73 */
+    if (ag->skip_rules == 0) *fus = 0;                                            /* :70-73 */
     else save = f->rconc[f->R - 1];                                               /* :76 */
     for (int r = 0; r < f->R; r++)                                                /* K7, :89-120 */
-        if (f->weights[r] > fr->weight_significant) {
+        if (f->weights[r] > ag->weight_significant) {
             double t = qdiff * f->weights[r];
             f->rconc[r] = qnow + t;
         }
-    if (fr->fus_is_rule_inserted) f->rconc[f->R - 1] = save;                      /* :124-126 */
+    if (*fus) f->rconc[f->R - 1] = save;                                          /* :124-126 */
 }
 
-/* src/frirl/frirl_update_sarsa.c:348-385 (check_possible_states :146-170, CHECK_STATES = 1) */
-void orc_update_sarsa(orc_frirl *fr, const double *q_ant, double reward, const double *cur_q_ant)
+/* src/frirl/frirl_update_sarsa.c:348-385 (check_possible_states :146-170, CHECK_STATES = 1).
+ * Bare form: rule base + agent parameters + the sticky fus_is_rule_inserted flag. */
+void orc_five_update_sarsa(orc_five *f, const orc_agent *ag, double *fus, const double *q_ant, double reward, const double *cur_q_ant)
 {
-    orc_five *f = fr->frb;
     double qp, qnow;
+    const int n = f->nant;
     orc_vag_concl(f, cur_q_ant, &qp);
     unsigned rule_i = orc_vag_concl(f, q_ant, &qnow);
-    double qdiff = fr->alpha * (reward + fr->gamma * qp - qnow);
-    if (qdiff > fr->qdiff_pos_boundary || qdiff < fr->qdiff_neg_boundary) {
+    double qdiff = ag->alpha * (reward + ag->gamma * qp - qnow);
+    if (qdiff > ag->qdiff_pos_boundary || qdiff < ag->qdiff_neg_boundary) {
         double rant[ORC_MAX_NANT], rconc = qnow;
-        for (int i = 0; i < fr->nstates; i++)
-            rant[i] = orc_check_possible_states(q_ant[i], fr->statedims[i].values, fr->statedims[i].values_len);
-        rant[fr->nstates] = orc_check_possible_states(q_ant[fr->nstates], fr->actiondim.values, fr->actiondim.values_len);
+        for (int i = 0; i < n; i++) rant[i] = orc_check_possible_states(q_ant[i], ag->grid[i], ag->grid_len[i]);
         rule_i = orc_vag_concl(f, rant, &rconc);
         if (rule_i == ~0u) {
-            fr->fus_is_rule_inserted = 1;
+            *fus = 1;
             orc_add_rule(f, rant, rconc + qdiff);
             return;
         }
-        fr->fus_is_rule_inserted = 0;
+        *fus = 0;
     }
-    orc_update_rules(fr, q_ant, qnow, qdiff);
+    orc_update_rules(f, ag, fus, q_ant, qnow, qdiff);
+}
+
+void orc_frirl_agent(const orc_frirl *fr, orc_agent *ag)
+{
+    memset(ag, 0, sizeof(*ag));
+    ag->alpha = fr->alpha; ag->gamma = fr->gamma;
+    ag->qdiff_pos_boundary = fr->qdiff_pos_boundary; ag->qdiff_neg_boundary = fr->qdiff_neg_boundary;
+    ag->weight_significant = fr->weight_significant; ag->skip_rules = fr->skip_rules;
+    for (int i = 0; i < fr->nstates; i++) { ag->grid[i] = fr->statedims[i].values; ag->grid_len[i] = fr->statedims[i].values_len; }
+    ag->grid[fr->nstates] = fr->actiondim.values; ag->grid_len[fr->nstates] = fr->actiondim.values_len;
+}
+
+void orc_update_sarsa(orc_frirl *fr, const double *q_ant, double reward, const double *cur_q_ant)
+{
+    orc_agent ag;
+    orc_frirl_agent(fr, &ag);
+    orc_five_update_sarsa(fr->frb, &ag, &fr->fus_is_rule_inserted, q_ant, reward, cur_q_ant);
 }
 
 /* src/frirl/frirl_episode.c:28-194.  The first action is chosen on the un-quantised default
@@ -987,4 +1008,8 @@ int orc_demo_run(int env, int trig_mode, const char *rb_path, uint64_t *hash, lo
     if (R) *R = fr->frb->R;
     orc_frirl_delete(fr);
     return ok;
+}
+void orc_frirl_set_trace(orc_frirl *fr, void (*cb)(orc_frirl *, int, double, const double *, const double *, void *))
+{
+    fr->trace = cb;
 }

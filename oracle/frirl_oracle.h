@@ -111,6 +111,17 @@ typedef struct orc_frirl {
     void *trace_ud;
 } orc_frirl;
 
+/* agent parameters of the SARSA update in bare form (any rule base) */
+typedef struct orc_agent {
+    double alpha, gamma, qdiff_pos_boundary, qdiff_neg_boundary, weight_significant;
+    int skip_rules;
+    const double *grid[ORC_MAX_NANT];   /* possible rule places per antecedent (states, then action) */
+    int grid_len[ORC_MAX_NANT];
+} orc_agent;
+unsigned orc_five_best_action(orc_five *f, const double *states, const double *action_ve, int A, double *actconc);
+void orc_five_update_sarsa(orc_five *f, const orc_agent *ag, double *fus, const double *q_ant, double reward, const double *cur_q_ant);
+void orc_frirl_agent(const orc_frirl *fr, orc_agent *ag);
+
 void orc_frirl_config(orc_frirl *fr, int env);     /* examples/<env>/<env>.c main(): hyper-parameters as data */
 int  orc_frirl_init(orc_frirl *fr);                /* frirl_init.c:29-341, frirl_init_ve.c:25-121, frirl_init_rb.c:86-147 */
 void orc_frirl_deinit(orc_frirl *fr);
@@ -167,6 +178,7 @@ unsigned orc_frirl_episode_num(orc_frirl *fr);
 int orc_frirl_ep_steps(orc_frirl *fr);
 double orc_frirl_ep_reward(orc_frirl *fr);
 void orc_frirl_hparams(orc_frirl *fr, double *out8);
+void orc_frirl_set_trace(orc_frirl *fr, void (*cb)(orc_frirl *, int, double, const double *, const double *, void *));
 int orc_demo_run(int env, int trig_mode, const char *rb_path, uint64_t *hash, long *steps, int *episodes, int *R);
 
 #ifdef __cplusplus

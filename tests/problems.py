@@ -71,6 +71,21 @@ class Batch:
                                          ob.dp(x.reshape(-1)), ob.dp(d.reshape(-1)), ob.ip(hit), nthreads)
         return d, hit
 
+    def five(self, e):
+        """Oracle rule base of environment e (its own copy)."""
+        n = int(self.nrules[e])
+        rant = np.ascontiguousarray(self.u[np.arange(self.nant)[:, None], self.uidx[e, :, :n]].T)
+        f = ob.Five(self.u.ravel(), self.ve.ravel(), self.nant, self.U, self.maxR, rant if n else None,
+                    np.ascontiguousarray(self.rb[e, self.nant, :n]) if n else None)
+        assert f.R == n
+        return f
+
+    def action_ve(self):
+        """VE values of the A actions used by orc_synth_rules' action column."""
+        A, U = self.A, self.U
+        idx = [0] if A == 1 else [(a * (U - 1)) // (A - 1) for a in range(A)]
+        return np.ascontiguousarray(self.ve[self.nant - 1, idx]), np.ascontiguousarray(self.u[self.nant - 1, idx])
+
     def to_device(self, device="cuda"):
         import torch
         import frirl_amd
@@ -83,3 +98,33 @@ def demo_batch(env, episodes, E=1):
     fr = ob.Frirl(env)
     fr.run(max_episodes=episodes + 1)
     return fr
+
+
+def demo_device_batch(env, episodes, E, seed=0):
+    """E copies of the rule base a demo has after `episodes` episodes (real tables / grids / hyper-parameters)
+    as a Batch-like object + the oracle agent.  Queries differ per environment."""
+    fr = demo_batch(env, episodes)
+    f = fr.five
+    b = Batch.__new__(Batch)
+    b.nant, b.U, b.E, b.A = f.nant, f.U, E, fr.nactions
+    R = f.R
+    b.maxR = R + 64 + ((R + 64) & 1)
+    b.u, b.ve = np.array(f.u), np.array(f.ve)
+    b.nrules = np.full(E, R, dtype=np.int32)
+    b.rb = np.zeros((E, f.nant + 1, b.maxR))
+    b.rb[:, : f.nant, :R] = f.veval[:, :R]
+    b.rb[:, f.nant, :R] = f.rconc[:R]
+    b.uidx = np.zeros((E, f.nant, b.maxR), dtype=np.uint32)
+    b.uidx[:, :, :R] = f.uidx[:, :R]
+    b.rant = np.array(f.rant[:R])
+    return b, fr
+
+
+def device_agent(fr, device="cuda", max_steps=1000):
+    """frirl_amd.Agent mirroring an oracle Frirl (its grids, hyper-parameters, per-action VE values)."""
+    import frirl_amd
+    hp = fr.hparams
+    dims = [fr.dim(k) for k in range(fr.nant)]
+    return frirl_amd.Agent(device, fr.nant, [d["values"] for d in dims], [d["values_div"] for d in dims],
+                           [d["values_def"] for d in dims], np.array(fr.action_vevalues), hp["alpha"], hp["gamma"], hp["qdiff_pos"],
+                           hp["qdiff_neg"], hp["weight_thr"], hp["skip_rules"], 0, fr.env, max_steps)

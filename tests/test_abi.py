@@ -41,6 +41,13 @@ def test_struct_layouts_match_header():
     assert C.sizeof(frirl_amd.RuleBases) == 24 and frirl_amd.RuleBases.rb.offset == 8 and frirl_amd.RuleBases.nrules.offset == 16
 
 
+def test_agent_and_envs_struct_layouts():
+    A, E = frirl_amd.AgentDesc, frirl_amd.EnvsDesc
+    assert A.skip_rules.offset == 40 and A.grid_len.offset == 64 and A.grid_div.offset == 128 and A.values_def.offset == 256
+    assert A.grid_values.offset == 384 and A.action_ve.offset == 392 and C.sizeof(A) == 400
+    assert C.sizeof(E) == 64 and E.status.offset == 56
+
+
 def test_argument_validation_and_no_cpu_fallback(lib):
     import torch
     t = frirl_amd.Tables(3, 41, 0, 0)

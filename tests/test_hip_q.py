@@ -1,0 +1,152 @@
+"""GPU parity of the Q-value kernels through the C ABI against the oracle.
+
+five_hip_vag_concl / five_hip_vag_concl_weight / frirl_hip_get_best_action
+(reference FIVEVagConcl.c:64-351, FIVEVagConclWeight.c:52-188, frirl_get_best_action.c:31-341).
+Bars: hit indices and arg-max actions BIT-EXACT; exact-hit Q values BIT-EXACT (a copy of the rule's
+consequent); interpolated Q values and weights within 1e-6 relative (north star) -- the tests assert a
+much tighter 1e-11, what the plain-double power + tree reduction actually deliver.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tests.problems import Batch, demo_device_batch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-11
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+
+
+CASES = [(3, 41, 8, 6, 3), (3, 41, 110, 40, 3), (5, 1001, 182, 24, 21), (5, 41, 367, 33, 3), (5, 41, 4097, 6, 3), (8, 101, 2500, 4, 5),
+         (2, 41, 300, 5, 3), (9, 41, 700, 3, 4)]
+
+
+@pytest.mark.parametrize("nant,U,R,E,A", CASES)
+def test_vag_concl_and_weights(nant, U, R, E, A):
+    import torch
+    b = Batch(nant, U, R, E, A=A, seed=7 + R, ragged=True)
+    b.nrules[b.nrules == 0] = 1          # Q of an empty rule base is 0/0 in the reference as well: not a parity case
+    x = b.queries(seed=R + 1, hit_fraction=0.4)
+    prob = b.to_device()
+    conc, hit = prob.vag_concl(dev(x))
+    w, hitw = prob.vag_concl_weight(dev(x))
+    torch.cuda.synchronize()
+    conc, hit, w, hitw = conc.cpu().numpy(), hit.cpu().numpy(), w.cpu().numpy(), hitw.cpu().numpy()
+    nh = 0
+    for e in range(E):
+        f = b.five(e)
+        n = f.R
+        h, c = f.vag_concl(x[e])
+        assert hit[e] == h and hitw[e] == h, e
+        if h >= 0:
+            nh += 1
+            assert c == conc[e], "exact hit returns the rule's consequent bit for bit"
+            assert np.isnan(w[e]).all(), "weights row of an exact-hit environment must stay untouched"
+        else:
+            assert rel(conc[e], c) <= RTOL, (e, conc[e], c)
+            assert f.vag_concl_weight(x[e]) == -1
+            assert rel(w[e, :n], f.weights[:n]).max() <= RTOL
+            assert abs(w[e, :n].sum() - 1.0) < 1e-12
+    assert 0 < nh < E or E < 8
+
+
+@pytest.mark.parametrize("nant,U,R,E,A", [c for c in CASES if 2 <= c[0] <= 9])
+def test_get_best_action(nant, U, R, E, A):
+    import torch
+    b = Batch(nant, U, R, E, A=A, seed=70 + R, ragged=True)
+    b.nrules[b.nrules == 0] = 1
+    ave, avals = b.action_ve()
+    x = b.queries(seed=R + 3, hit_fraction=0.5)
+    # on-grid action values in the hitting queries so that exact hits occur for one action only
+    prob = b.to_device()
+    states = np.ascontiguousarray(x[:, : nant - 1])
+    actconc, best = prob.get_best_action(dev(states), dev(ave))
+    torch.cuda.synchronize()
+    actconc, best = actconc.cpu().numpy(), best.cpu().numpy()
+    for e in range(E):
+        f = b.five(e)
+        bo, ac = f.best_action(states[e], ave)
+        assert rel(actconc[e], ac).max() <= RTOL, (e, actconc[e], ac)
+        srt = np.sort(ac)
+        if len(srt) > 1 and (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
+            assert best[e] == bo, (e, actconc[e], ac)
+        else:   # numerically tied maxima: the GPU may only pick among the tied ones
+            assert abs(ac[best[e]] - srt[-1]) <= 1e-9 * max(1.0, abs(srt[-1]))
+
+
+def test_get_best_action_exact_ties_pick_first():
+    """The observed state hits one rule per action with equal consequents => exactly tied Q values =>
+    the FIRST maximum (index 0) wins (reference src/inl/max.inl:21, strict <)."""
+    import torch
+    b = Batch(3, 41, 256, 4, A=3, seed=5, ragged=False)
+    U = b.U
+    aidx = [0, (U - 1) // 2, U - 1]
+    for e in range(b.E):
+        for a in range(3):          # rules 10, 11, 12: same state, the three actions, same Q
+            r = 10 + a
+            b.uidx[e, :2, r] = b.uidx[e, :2, 10]
+            b.uidx[e, 2, r] = aidx[a]
+            b.rb[e, :3, r] = b.ve[np.arange(3), b.uidx[e, :, r]]
+            b.rb[e, 3, r] = 7.0 + e
+    ave, _ = b.action_ve()
+    states = np.ascontiguousarray(b.u[np.arange(2), b.uidx[:, :2, 10]])
+    prob = b.to_device()
+    actconc, best = prob.get_best_action(dev(states), dev(ave))
+    torch.cuda.synchronize()
+    assert (best.cpu().numpy() == 0).all()
+    assert (actconc.cpu().numpy() == (7.0 + np.arange(b.E))[:, None]).all()
+    for e in range(b.E):
+        bo, ac = b.five(e).best_action(states[e], ave)
+        assert bo == 0 and (ac == 7.0 + e).all()
+
+
+@pytest.mark.parametrize("env,episodes", [("mountaincar", 6), ("cartpole", 9), ("acrobot", 5)])
+def test_demo_rulebases(env, episodes):
+    """Real demo tables / rule bases: quantised on-grid states (mostly exact hits) and off-grid states."""
+    import torch
+    E = 48
+    b, fr = demo_device_batch(env, episodes, E)
+    f = fr.five
+    rng = np.random.default_rng(3)
+    nant = f.nant
+    x = np.zeros((E, nant))
+    for e in range(E):
+        for k in range(nant):
+            vals = fr.dim(k)["values"]
+            x[e, k] = vals[rng.integers(len(vals))]
+        if e % 3 == 0:      # an existing rule: exact hit
+            x[e] = b.rant[rng.integers(len(b.rant))]
+        if e % 3 == 2:      # off-grid state, on-grid action
+            for k in range(nant - 1):
+                vals = fr.dim(k)["values"]
+                x[e, k] = rng.uniform(vals[0], vals[-1])
+    prob = b.to_device()
+    conc, hit = prob.vag_concl(dev(x))
+    ave = np.array(fr.action_vevalues)
+    actconc, best = prob.get_best_action(dev(np.ascontiguousarray(x[:, : nant - 1])), dev(ave))
+    torch.cuda.synchronize()
+    conc, hit, actconc, best = conc.cpu().numpy(), hit.cpu().numpy(), actconc.cpu().numpy(), best.cpu().numpy()
+    hits = 0
+    for e in range(E):
+        h, c = f.vag_concl(x[e])
+        assert hit[e] == h
+        if h >= 0:
+            hits += 1
+            assert conc[e] == c
+        else:
+            assert rel(conc[e], c) <= RTOL
+        bo = fr.get_best_action(x[e, : nant - 1])
+        ac = np.array(fr.actconc)
+        assert rel(actconc[e], ac).max() <= RTOL
+        srt = np.sort(ac)
+        if (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
+            assert best[e] == bo
+    assert hits > 0
