@@ -57,8 +57,35 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+HOST_DIR = os.path.join(PKG, "host")
+DROPIN_LIB = os.path.join(LIBDIR, "libfrirl_dropin.so")
+DEMO_BIN = os.path.join(LIBDIR, "frirl_demo")
+CC = os.environ.get("CC", "gcc")
+# ANSI C host: no FMA contraction, same optimisation level as the reference (CMakeLists.txt:6)
+HOST_CFLAGS = ["-O2", "-std=gnu99", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-parameter"]
+
+
+def build_host(force=False, verbose=False):
+    """libfrirl_dropin.so: the reference's five_* / FIVE_* / frirl_* C API on top of libfrirl_hip.so; + the demo driver."""
+    srcs = [os.path.join(HOST_DIR, f) for f in ("five_host.c", "frirl_host.c", "frirl_io.c")]
+    deps = srcs + glob.glob(os.path.join(HOST_DIR, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + [HIP_LIB]
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST_DIR]
+    if force or _stale(DROPIN_LIB, deps):
+        cmd = [CC] + HOST_CFLAGS + inc + ["-shared", "-o", DROPIN_LIB] + srcs + ["-L", LIBDIR, "-lfrirl_hip", "-Wl,-rpath,$ORIGIN", "-lm"]
+        if verbose:
+            print("+", " ".join(cmd))
+        subprocess.run(cmd, check=True)
+    demo_src = os.path.join(HOST_DIR, "demo.c")
+    if force or _stale(DEMO_BIN, [demo_src, DROPIN_LIB]):
+        cmd = [CC] + HOST_CFLAGS + inc + ["-o", DEMO_BIN, demo_src, "-L", LIBDIR, "-lfrirl_dropin", "-lfrirl_hip", "-Wl,-rpath,$ORIGIN", "-lm"]
+        if verbose:
+            print("+", " ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return [DROPIN_LIB, DEMO_BIN]
+
+
 def build_all(force=False, verbose=False):
-    return [build_hip(force, verbose)]
+    return [build_hip(force, verbose)] + build_host(force, verbose)
 
 
 if __name__ == "__main__":

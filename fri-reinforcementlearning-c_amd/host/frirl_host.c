@@ -1,0 +1,363 @@
+/*
+ * frirl_host.c -- host side of the FRIRL agent (ANSI C), MI355X drop-in for the reference's libfrirl.
+ *
+ * Exports the reference's agent API (include/frirl.h == reference src/frirl/frirl.h:42-64).  The RL
+ * driver (init, episode loop with the application's host callbacks, convergence test) is host code as
+ * in the reference; the two hot calls of every environment step -- frirl_get_best_action and
+ * frirl_update_sarsa -- are each ONE fused GPU call on the rule base's device mirror.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include "dropin_internal.h"
+
+void five_dropin_note_appended(struct FIVERB *frb, const double *rant, double rconc);
+
+/* ---- initialisation ----------------------------------------------------------------------------- */
+
+/* reference src/frirl/frirl_init_ve.c:25-121: scaling points (value, steep, steep) per state grid value;
+ * action scaling points at i*2/(A-1)-1 with steepness (A-1)/2 in INTEGER arithmetic (:91-92). */
+int frirl_init_ve(struct frirl_desc *frirl, fri_float *ve, fri_float *u, int univlength)
+{
+    int st, i, c;
+    double *scf = MALLOC(sizeof(double) * univlength), *row;
+    if (!scf) return -1;
+    for (st = 0; st <= frirl->statedims_len; st++) {
+        const int is_action = (st == frirl->statedims_len);
+        const int n = is_action ? frirl->actiondim.values_len : frirl->statedims[st].values_len;
+        double *sp = MALLOC(sizeof(double) * 3 * n);
+        if (!sp) return -1;
+        if (is_action) {
+            const double divratio = 1.0 / (n - 1) * 2.0;
+            for (i = 0; i < n; i++) { sp[3 * i] = i * divratio - 1.0; sp[3 * i + 1] = sp[3 * i + 2] = (n - 1) / 2; }
+        } else {
+            for (c = 0; c < n; c++) { sp[3 * c] = frirl->statedims[st].values[c]; sp[3 * c + 1] = sp[3 * c + 2] = frirl->statedims[st].values_steep; }
+        }
+        FIVE_GSc_func(u + st * univlength, 1, univlength, sp, n, 3, NAN, scf);
+        free(sp);
+        row = FIVEGVagEnv(u + st * univlength, 1, univlength, scf);
+        if (!row) return -1;
+        memcpy(ve + st * univlength, row, sizeof(double) * univlength);
+        free(row);
+    }
+    free(scf);
+    return 0;
+}
+
+/* reference src/frirl/frirl_init_rb.c:86-147: the 2^nant corner rules (min/max of every grid), Q = 0 */
+int frirl_init_rb(struct frirl_desc *frirl, fri_float *rant, fri_float *rconc, int *numofrules)
+{
+    const int n = frirl->numofantecedents;
+    int i, j, c;
+    *numofrules = (int)pow(2, n);
+    for (j = 0; j < *numofrules; j++) rconc[j] = 0.0;
+    for (i = 0; i < n; i++) {
+        const struct frirl_dimension_desc *d = (i < frirl->statedims_len) ? &frirl->statedims[i] : &frirl->actiondim;
+        double mn = d->values[0], mx = d->values[0];
+        const unsigned int divider = (unsigned int)*numofrules >> (i + 1);
+        for (c = 0; c < d->values_len; c++) { if (d->values[c] > mx) mx = d->values[c]; if (d->values[c] < mn) mn = d->values[c]; }
+        for (j = 0; j < *numofrules; j++) rant[j * n + i] = (((j / divider) % 2) == 0) ? mn : mx;
+    }
+    return 0;
+}
+
+/* reference src/frirl/frirl_init.c:29-341 */
+int frirl_init(struct frirl_desc *frirl)
+{
+    struct timeval t1;
+    struct FIVERB *frb;
+    const int usize = frirl->statedims[0].universe_len, ns = frirl->statedims_len;
+    int i, j, k, numofrules, nant;
+    fri_float *u, *ve, *rant, *rconc;
+
+    frirl->numofantecedents = nant = ns + 1;
+    u = MALLOC(sizeof(fri_float) * usize * nant);
+    ve = MALLOC(sizeof(fri_float) * usize * nant);
+    rant = MALLOC(sizeof(fri_float) * (size_t)frirl->five_maxnumofrules * nant);
+    rconc = MALLOC(sizeof(fri_float) * frirl->five_maxnumofrules);
+    if (!u || !ve || !rant || !rconc) return -1;
+    memset(rant, 0, sizeof(fri_float) * (size_t)frirl->five_maxnumofrules * nant);
+    memset(rconc, 0, sizeof(fri_float) * frirl->five_maxnumofrules);
+    for (i = 0; i < ns; i++) memcpy(u + i * usize, frirl->statedims[i].universe, sizeof(fri_float) * usize);
+    memcpy(u + ns * usize, frirl->actiondim.universe, sizeof(fri_float) * usize);
+
+    frirl->possible_states = MALLOC(sizeof(struct frirl_values_desc) * ns);
+    frirl->possible_actions = MALLOC(sizeof(struct frirl_values_desc));
+    if (!frirl->possible_states || !frirl->possible_actions) return -1;
+    for (i = 0; i < ns; i++) {
+        struct frirl_values_desc *pv = &frirl->possible_states[i];
+        pv->values_len = frirl->statedims[i].values_len;
+        pv->values = MALLOC(sizeof(double) * pv->values_len);
+        pv->vevalues = NULL;
+        if (!pv->values) return -1;
+        memcpy(pv->values, frirl->statedims[i].values, sizeof(double) * pv->values_len);
+        pv->epsilon = frirl->statedims[i].values_div;
+    }
+    frirl->possible_actions->values_len = frirl->actiondim.values_len;
+    frirl->possible_actions->values = MALLOC(sizeof(fri_float) * frirl->actiondim.values_len);
+    frirl->possible_actions->vevalues = MALLOC(sizeof(fri_float) * frirl->actiondim.values_len);
+    if (!frirl->possible_actions->values || !frirl->possible_actions->vevalues) return -1;
+    memcpy(frirl->possible_actions->values, frirl->actiondim.values, sizeof(fri_float) * frirl->actiondim.values_len);
+    frirl->possible_actions->epsilon = frirl->actiondim.values_div;
+
+    frirl->reduction_state = 0;
+    if (frirl_init_ve(frirl, ve, u, usize) != 0) return -1;
+    frirl_init_rb(frirl, rant, rconc, &numofrules);
+    frirl->fiverb = frb = FIVEInit(u, ve, 0, nant, usize, numofrules, frirl->five_maxnumofrules, nant + 1, rant, rconc);
+    if (!frb) return -1;
+
+    frirl->reward.ep_total_value = -1;
+    frirl->reward.ep_total_steps = -1;
+    frirl->fus_is_rule_inserted = 0;
+    frirl->fiverb_vea = ve + usize * ns;
+    frirl->fiverb_ua = u + usize * ns;
+    /* VE value of every action; the reference passes len = uksize = U-1 here (frirl_init.c:156-158) */
+    for (j = 0; j < frirl->actiondim.values_len; j++)
+        frirl->possible_actions->vevalues[j] = frirl->fiverb_vea[five_dropin_snap(frirl->fiverb_ua, (int)frb->uksize, frirl->possible_actions->values[j], frb->udivs[nant - 1])];
+
+    /* parameter sanity checks (frirl_init.c:160-208) */
+    for (k = 0; k < nant; k++) {
+        const struct frirl_values_desc *pv = (k < ns) ? &frirl->possible_states[k] : frirl->possible_actions;
+        if ((frb->uk[k][usize - 1] - frb->uk[k][0]) == 0.0) { printf("frirl_init: FATAL ERROR: U dimension %d max-min=0.0!\n", k); exit(1); }
+        if (pv->values[0] < frb->uk[k][0] || pv->values[pv->values_len - 1] > frb->uk[k][usize - 1]) {
+            printf("frirl_init: FATAL ERROR: the grid of dimension %d [%f, %f] leaves its universe [%f, %f]\n", k, pv->values[0],
+                   pv->values[pv->values_len - 1], frb->uk[k][0], frb->uk[k][usize - 1]);
+            exit(1);
+        }
+        if (pv->values_len > FRIRL_HIP_MAX_GRID) { printf("frirl_init: FATAL ERROR: dimension %d has %d grid values (max %d)\n", k, pv->values_len, FRIRL_HIP_MAX_GRID); exit(1); }
+    }
+
+    /* scratch the reference hangs off the descriptor; kept because applications may read fgba_actconc */
+    frirl->fgba_vagdist_states = calloc((size_t)(frirl->five_maxnumofrules + 4) * ns, sizeof(fri_float));
+    frirl->fgba_ruledist = calloc(frirl->five_maxnumofrules, sizeof(fri_float));
+    frirl->fgba_actconc = calloc(frirl->five_maxnumofrules, sizeof(fri_float));
+    frirl->fgba_dists = calloc(4 * FIVE_MAX_NUM_OF_UNIVERSES, sizeof(fri_float));
+    frirl->fgba_statedistsum = calloc(frirl->five_maxnumofrules, sizeof(fri_float));
+    frirl->fus_values = calloc(frb->rulelength, sizeof(fri_float));
+    frirl->fus_proposed_values = calloc(frb->rulelength, sizeof(fri_float));
+    frirl->fus_check_states = calloc(nant, sizeof(fri_float));
+    frirl->fep_ant = calloc(nant, sizeof(fri_float));
+    frirl->fep_cur_ant = calloc(nant, sizeof(fri_float));
+    frirl->fep_q_ant = calloc(nant, sizeof(fri_float));
+    frirl->fep_cur_q_ant = calloc(nant, sizeof(fri_float));
+    if (!frirl->fgba_vagdist_states || !frirl->fgba_ruledist || !frirl->fgba_actconc || !frirl->fgba_dists || !frirl->fgba_statedistsum ||
+        !frirl->fus_values || !frirl->fus_proposed_values || !frirl->fus_check_states || !frirl->fep_ant || !frirl->fep_cur_ant ||
+        !frirl->fep_q_ant || !frirl->fep_cur_q_ant)
+        return -1;
+
+    frirl->is_running = 1;
+    frirl->episode_num = 1;
+    gettimeofday(&t1, NULL);
+    srand((unsigned int)(t1.tv_usec * t1.tv_sec));
+    return 0;
+}
+
+/* reference src/frirl/frirl_deinit.c:18-60 */
+void frirl_deinit(struct frirl_desc *frirl)
+{
+    int i;
+    double *u = frirl->fiverb->u, *ve = frirl->fiverb->ve, *rant = frirl->fiverb->rant, *rconc = frirl->fiverb->rconc;
+    five_deinit(frirl->fiverb);
+    free(u); free(ve); free(rant); free(rconc);
+    free(frirl->fus_proposed_values); free(frirl->fus_values); free(frirl->fus_check_states);
+    free(frirl->fgba_statedistsum); free(frirl->fgba_vagdist_states); free(frirl->fgba_ruledist); free(frirl->fgba_actconc); free(frirl->fgba_dists);
+    free(frirl->fep_ant); free(frirl->fep_cur_ant); free(frirl->fep_q_ant); free(frirl->fep_cur_q_ant);
+    for (i = 0; i < frirl->statedims_len; i++) free(frirl->possible_states[i].values);
+    free(frirl->possible_states);
+    free(frirl->possible_actions->values); free(frirl->possible_actions->vevalues); free(frirl->possible_actions);
+    if (frirl->rbfile) free(frirl->rbfile);
+}
+
+/* ---- action selection --------------------------------------------------------------------------- */
+
+/* reference src/frirl/frirl_get_best_action.c:31-341: one fused GPU sweep evaluates all actions */
+unsigned int frirl_get_best_action(struct frirl_desc *frirl, fri_float *states)
+{
+    uint32_t best;
+    int rc = five_hip_mirror_get_best_action(five_dropin_mirror(frirl->fiverb), states, frirl->possible_actions->vevalues,
+                                             frirl->actiondim.values_len, frirl->fgba_actconc, &best);
+    if (rc) five_dropin_fatal("frirl_get_best_action", rc);
+    return (unsigned int)best;
+}
+
+/* reference src/frirl/frirl_e_greedy_selection.c:21-37; the random index is clamped to A-1 (the
+ * reference can return A, one past the last action -- SURVEY Appendix C "fix") */
+unsigned int frirl_e_greedy_selection(struct frirl_desc *frirl, fri_float *states)
+{
+    double r;
+    unsigned int a;
+    if (frirl->no_random == 1 || frirl->epsilon == 0.0) return frirl_get_best_action(frirl, states);
+    r = (double)rand() / (double)RAND_MAX;
+    if (r > frirl->epsilon) return frirl_get_best_action(frirl, states);
+    a = (unsigned int)round((double)rand() / (double)RAND_MAX * frirl->actiondim.values_len);
+    if (a >= (unsigned int)frirl->actiondim.values_len) a = (unsigned int)frirl->actiondim.values_len - 1;
+    return a;
+}
+
+/* reference src/frirl/frirl_check_possible_states.c:96-122 (+ :53-88): nearest allowed grid value, ties
+ * to the upper neighbour; the grid-refinement branch (:68-75) cannot trigger with epsilon = values_div */
+fri_float frirl_check_possible_states(struct frirl_desc *frirl, fri_float observation, struct frirl_values_desc *pv)
+{
+    int i;
+    (void)frirl;
+    for (i = 0; i < pv->values_len; i++) if (observation < pv->values[i]) break;
+    if (i == pv->values_len) return pv->values[pv->values_len - 1];
+    if (i == 0) return pv->values[0];
+    i--;
+    return ((observation - pv->values[i]) < (pv->values[i + 1] - observation)) ? pv->values[i] : pv->values[i + 1];
+}
+
+/* ---- SARSA update -------------------------------------------------------------------------------- */
+
+/* reference src/frirl/frirl_update_sarsa.c:348-385: the whole TD step (Q(s',a'), Q(s,a), qdiff, grid snap,
+ * append or exact / weighted write-back) is one fused GPU call; the host mirrors its bookkeeping. */
+void frirl_update_sarsa(struct frirl_desc *frirl, fri_float *q_ant, fri_float reward, fri_float *cur_q_ant)
+{
+    struct FIVERB *frb = frirl->fiverb;
+    frirl_hip_agent ag;
+    static double grid[FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID];
+    double new_rant[FRIRL_HIP_MAX_NANT], new_rconc = 0.0;
+    int32_t fus = (frirl->fus_is_rule_inserted != 0.0), status = 0;
+    const int n = frirl->numofantecedents;
+    int k, rc;
+
+    memset(&ag, 0, sizeof ag);
+    ag.alpha = frirl->alpha; ag.gamma = frirl->gamma;
+    ag.qdiff_pos_boundary = frirl->qdiff_pos_boundary; ag.qdiff_neg_boundary = frirl->qdiff_neg_boundary;
+    ag.weight_significant = frirl->rule_weight_considered_significant_for_update;
+    ag.skip_rules = frirl->skip_rules; ag.p = frb->p; ag.A = frirl->actiondim.values_len;
+    for (k = 0; k < n; k++) {
+        const struct frirl_values_desc *pv = (k < frirl->statedims_len) ? &frirl->possible_states[k] : frirl->possible_actions;
+        ag.grid_len[k] = pv->values_len;
+        memcpy(grid + k * FRIRL_HIP_MAX_GRID, pv->values, sizeof(double) * pv->values_len);
+    }
+    ag.grid_values = grid;
+    rc = five_hip_mirror_update_sarsa(five_dropin_mirror(frb), &ag, q_ant, reward, cur_q_ant, &fus, &status, new_rant, &new_rconc, frb->rconc);
+    if (rc) five_dropin_fatal("frirl_update_sarsa", rc);
+    if (status == FRIRL_HIP_UPD_INSERTED) five_dropin_note_appended(frb, new_rant, new_rconc);
+    else if (status == FRIRL_HIP_UPD_FULL) fprintf(stderr, "frirl_update_sarsa: rule base full (%d rules), new rule dropped\n", frb->numofrules);
+    frirl->fus_is_rule_inserted = (fri_float)fus;
+}
+
+/* ---- episode ------------------------------------------------------------------------------------- */
+
+void getActionFromTerminal(struct frirl_desc *frirl);
+
+/* reference src/frirl/frirl_episode.c:28-194 */
+void frirl_episode(struct frirl_desc *frirl)
+{
+    const int ns = frirl->statedims_len, n = frirl->numofantecedents;
+    fri_float *q_ant = frirl->fep_q_ant, *cur_q_ant = frirl->fep_cur_q_ant;
+    fri_float *states = frirl->fep_ant, *cur_states = frirl->fep_cur_ant;
+    unsigned int a, ap;
+    int i, step;
+
+    for (i = 0; i < ns; i++) q_ant[i] = states[i] = frirl->statedims[i].values_def;
+    frirl->reward.ep_total_value = 0;
+    frirl->reward.ep_total_steps = 0;
+    if (frirl->original_learning == 0) {               /* imitation: a key, or space for the greedy action */
+        getActionFromTerminal(frirl);
+        a = (frirl->keyaction == 32 || frirl->keyaction >= (unsigned int)frirl->actiondim.values_len) ? frirl_e_greedy_selection(frirl, states) : frirl->keyaction;
+    } else {
+        a = frirl_e_greedy_selection(frirl, states);   /* on the un-quantised default state (:78) */
+    }
+    q_ant[ns] = frirl->actiondim.values[a];
+
+    for (step = 1; step <= frirl->max_steps; step++) {
+        frirl->do_action_func(frirl, q_ant[ns], states, ns, cur_states);
+        frirl->get_reward_func(frirl, cur_states, ns, &frirl->reward);
+        frirl->reward.ep_total_value += frirl->reward.value;
+        frirl->quant_obs_func(frirl, cur_states, ns, cur_q_ant);
+        if (frirl->original_learning == 0) {
+            getActionFromTerminal(frirl);
+            ap = (frirl->keyaction == 32 || frirl->keyaction >= (unsigned int)frirl->actiondim.values_len) ? frirl_e_greedy_selection(frirl, cur_q_ant) : frirl->keyaction;
+        } else {
+            ap = frirl_e_greedy_selection(frirl, cur_q_ant);
+        }
+        cur_q_ant[ns] = frirl->actiondim.values[ap];
+        if (frirl->reduction_state == 0) frirl_update_sarsa(frirl, q_ant, frirl->reward.value, cur_q_ant);
+        for (i = 0; i < ns; i++) states[i] = cur_states[i];
+        for (i = 0; i < n; i++) q_ant[i] = cur_q_ant[i];
+        frirl->reward.ep_total_steps++;
+        if (frirl->reward.success == 1) break;
+    }
+}
+
+/* ---- run modes ------------------------------------------------------------------------------------ */
+
+/* reference src/frirl/frirl_sequential_run.c:24-165: incremental construction until the rule base,
+ * step count and reward repeat and no consequent moved by >= qdiff_final_tolerance.  The reduction
+ * phase (:170-350) is the next widening step and is not built yet. */
+void frirl_sequential_run(struct frirl_desc *frirl)
+{
+    struct FIVERB *frb = frirl->fiverb;
+    double *prev_rconc = MALLOC(sizeof(double) * frirl->five_maxnumofrules);
+    int epchunk = 1, i;
+    const int maxep = (frirl->runmode == FRIRL_MPI || frirl->runmode == FRIRL_OMP) ? FRIRL_AGENT_EPCHUNK : frirl->max_episodes;
+    frirl->epended = 0;
+    if (frirl->construct_rb == 1) {
+        for (;;) {
+            int prev_numru, prev_steps, epend = 0;
+            double prev_reward;
+            if (!(epchunk < maxep)) {
+                if (!(frirl->episode_num < (unsigned int)frirl->max_episodes)) frirl->is_running = 0;
+                break;
+            }
+            prev_numru = frb->numofrules;
+            prev_reward = frirl->reward.ep_total_value;
+            prev_steps = frirl->reward.ep_total_steps;
+            memcpy(prev_rconc, frb->rconc, sizeof(double) * frirl->five_maxnumofrules);
+
+            frirl_episode(frirl);
+
+            printf("#%d Episode: %d\tSteps: %d\tReward: %s%f%s\tRules: %d\n", frirl->agent_id, frirl->episode_num, frirl->reward.ep_total_steps,
+                   frirl->reward.ep_total_value > frirl->reward_good_above ? TERM_GREEN : TERM_RED, frirl->reward.ep_total_value, TERM_NC,
+                   frb->numofrules);
+
+            if ((prev_numru == frb->numofrules && prev_steps == frirl->reward.ep_total_steps &&
+                 frirl->reward.ep_total_value > frirl->reward_good_above && prev_reward == frirl->reward.ep_total_value) || frirl->user_exited == 1) {
+                epend = 1;
+                frirl->epended = 1;
+                if (frirl->verbose > 0) printf("Rule-base size and reward are the same as in the previous iteration.\n");
+                for (i = 0; i < frb->numofrules; i++) {
+                    if (fabs(frb->rconc[i] - prev_rconc[i]) >= frirl->qdiff_final_tolerance) {
+                        epend = 0;
+                        if (frirl->verbose > 0) printf("Greater at rule %d. %.18f - %.18f = %.18f (max: %.18f)\n", i, frb->rconc[i], prev_rconc[i], frb->rconc[i] - prev_rconc[i], frirl->qdiff_final_tolerance);
+                        else break;
+                    }
+                }
+            }
+            if (epend == 1 || frirl->user_exited == 1) {
+                frirl->is_running = 0;
+                printf("-----------------------------------------------------------------\n");
+                printf("No more significant changes in rule-base. RB considered complete.\n");
+                printf("-----------------------------------------------------------------\n");
+                break;
+            }
+            frirl->episode_num++;
+            epchunk++;
+        }
+    }
+    if (frirl->reduce_rb == 1)
+        printf("frirl_sequential_run: rule-base reduction is not part of this MI355X hot-path build (reference frirl_sequential_run.c:170-350); skipped.\n");
+    free(prev_rconc);
+}
+
+/* reference src/frirl/frirl_agent.c:294-467: experimental OpenMP / MPI agent modes, off by default in
+ * the reference build and outside the hot path.  Many agents run through the batched GPU API instead. */
+void frirl_omp_run(struct frirl_desc *frirl)
+{
+    printf("frirl_omp_run: not available in the MI355X build; use the batched frirl_hip_* API for many agents. Running sequentially.\n");
+    frirl->runmode = FRIRL_SEQ;
+    frirl_sequential_run(frirl);
+}
+
+void frirl_mpi_run(struct frirl_desc *frirl)
+{
+    printf("frirl_mpi_run: not available in the MI355X build; use the batched frirl_hip_* API for many agents. Running sequentially.\n");
+    frirl->runmode = FRIRL_SEQ;
+    frirl_sequential_run(frirl);
+}

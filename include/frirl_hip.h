@@ -196,6 +196,49 @@ int frirl_hip_episode_begin(const frirl_hip_tables *t, const frirl_hip_rulebases
 int frirl_hip_episode_step(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                            const frirl_hip_envs *envs, void *stream);
 
+/* ---- FIVEVagConcl_FRIRL_BestAct (reference src/five/FIVEVagConcl_FRIRL_BestAct.c:56-299) -------
+ * Conclusion from PRECOMPUTED rule distances: first exact hit (d == 0) or Shepard interpolation.
+ *   ruledists [dev][E][maxR], conc [dev][E] */
+int five_hip_bestact(const frirl_hip_rulebases *b, int nant, int p, const double *ruledists, double *conc, void *stream);
+
+/* =================================================================================================
+ * Single rule base, HOST buffers: the form the ANSI-C drop-in library (libfive / libfrirl
+ * replacement under fri-reinforcementlearning-c_amd/host/) calls.  A mirror is the device-resident
+ * copy of ONE struct FIVERB (tables + rule slab in HBM, E = 1) plus pinned staging buffers and a
+ * private stream; every call below takes and returns HOST pointers and returns after the result is
+ * in host memory.  Same kernels as the batched entry points above.
+ * ================================================================================================= */
+typedef struct five_hip_mirror five_hip_mirror;
+
+/* FIVEInit (reference src/five/FIVEInit.c:55-347): u, ve are host [nant][U]; p <= 0 -> nant. */
+five_hip_mirror *five_hip_mirror_create(int32_t nant, int32_t U, const double *u, const double *ve, int32_t maxR, int32_t p);
+void five_hip_mirror_destroy(five_hip_mirror *m);
+/* replace the whole rule base: veval is host SoA [nant][ld] (FIVERB.rseqant_veval rows), rconc host [R] */
+int five_hip_mirror_upload(five_hip_mirror *m, int32_t R, const double *const *veval_rows, const double *rconc);
+/* FIVE_add_rule (five_add_rule.c:47-95): append one rule given its raw antecedents (host [nant]) */
+int five_hip_mirror_add_rule(five_hip_mirror *m, const double *rant, double rconc);
+/* five_remove_rule (five_remove_rule.c:29-85): delete rule r, compacting the slab */
+int five_hip_mirror_remove_rule(five_hip_mirror *m, uint32_t r);
+/* overwrite the consequents with host values (callers that edit FIVERB.rconc on the host) */
+int five_hip_mirror_set_rconc(five_hip_mirror *m, const double *rconc, int32_t R);
+int five_hip_mirror_get_rconc(five_hip_mirror *m, double *rconc, int32_t R);
+int32_t five_hip_mirror_numofrules(const five_hip_mirror *m);
+/* five_rule_distance: ruledists host [>= R] (may be NULL); *hit = index or FRIRL_HIP_NO_HIT */
+int five_hip_mirror_rule_distance(five_hip_mirror *m, const double *x, double *ruledists, uint32_t *hit);
+int five_hip_mirror_vag_concl(five_hip_mirror *m, const double *x, double *conc, uint32_t *hit);
+int five_hip_mirror_vag_concl_weight(five_hip_mirror *m, const double *x, double *weights, uint32_t *hit);
+int five_hip_mirror_bestact(five_hip_mirror *m, const double *ruledists, double *conc);
+/* frirl_get_best_action: states host [nant-1], action_ve host [A], actconc host [A] */
+int five_hip_mirror_get_best_action(five_hip_mirror *m, const double *states, const double *action_ve, int32_t A,
+                                    double *actconc, uint32_t *best);
+/* frirl_update_sarsa: `agent` with HOST grid_values [nant][FRIRL_HIP_MAX_GRID] (action_ve unused);
+ * *fus in/out; *status = FRIRL_HIP_UPD_*; when a rule was appended its raw antecedents are written to
+ * new_rant (host [nant]) and its consequent to *new_rconc; rconc (host [>= numofrules]) receives the
+ * consequents after the update. */
+int five_hip_mirror_update_sarsa(five_hip_mirror *m, const frirl_hip_agent *agent, const double *q_ant, double reward,
+                                 const double *cur_q_ant, int32_t *fus, int32_t *status, double *new_rant, double *new_rconc,
+                                 double *rconc);
+
 #ifdef __cplusplus
 }
 #endif

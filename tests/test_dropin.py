@@ -1,0 +1,103 @@
+"""The ANSI-C drop-in library (libfrirl_dropin.so: the reference's five_* / FIVE_* / frirl_* API on top of
+the HIP C ABI).
+
+CPU part: the library builds, exports the reference's full symbol surface (SURVEY 8b `nm -g` list), and --
+when the reference tree is present (build container) -- the reference's UNCHANGED example sources compile
+against include/*.h and link against it ("examples/ link unchanged", BASELINE north star).
+GPU part: tests/test_ALL.sh-equivalent parity: the three demos run through the drop-in API on the MI355X
+and their final rule bases are compared with the oracle-validated dumps of the genuine reference
+(tests/golden/ref_*.frirlrb.txt) and with the reference's own golden files (tests/golden/orig/).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import frirl_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "fri-reinforcementlearning-c_amd", "lib")
+REF = "/root/reference"
+
+FIVE_SYMS = """FIVEInit FIVEGScFunc FIVE_GSc_func FIVEGVagEnv FIVEValVag FIVEVagConcl FIVE_vag_concl FIVEVagConclWeight
+FIVE_vag_concl_weight FIVEVagConcl_FRIRL_BestAct FIVEAddRule five_add_rule FIVE_add_rule five_remove_rule five_rule_distance
+five_vague_distance five_vague_distance_parallel five_deinit""".split()
+FRIRL_SYMS = """frirl_init frirl_deinit frirl_init_ve frirl_init_rb frirl_episode frirl_e_greedy_selection frirl_get_best_action
+frirl_check_possible_states frirl_update_sarsa frirl_sequential_run frirl_omp_run frirl_mpi_run frirl_test_run frirl_run
+frirl_gen_fixres_arr frirl_visualization_init frirl_visualization_deinit frirl_show_rb frirl_show_hex_rb frirl_save_rb_to_text_file
+frirl_save_rb_to_bin_file frirl_load_rb_from_bin_file frirl_print_usage frirl_parse_cmdline getch getActionFromTerminal""".split()
+
+
+@pytest.fixture(scope="module")
+def built():
+    frirl_amd.build()
+    return os.path.join(LIBDIR, "libfrirl_dropin.so"), os.path.join(LIBDIR, "frirl_demo")
+
+
+def test_dropin_exports_reference_surface(built):
+    lib, demo = built
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], check=True, capture_output=True, text=True).stdout
+    have = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    missing = [s for s in FIVE_SYMS + FRIRL_SYMS if s not in have]
+    assert not missing, missing
+    assert os.access(demo, os.X_OK)
+
+
+def test_struct_layouts_match_reference_abi(tmp_path):
+    """offsetof/sizeof of the ABI structs (measured against the reference headers)."""
+    src = tmp_path / "lay.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "frirl_types_def.h"\n#include "frirl_app_helpers.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(struct FIVERB), offsetof(struct FIVERB,ruledists),'
+                   'offsetof(struct FIVERB,rseqant_veval), offsetof(struct FIVERB,rconc), offsetof(struct FIVERB,udivs), offsetof(struct FIVERB,avx2_rbsize),'
+                   'sizeof(struct frirl_dimension_desc), sizeof(struct frirl_values_desc), sizeof(struct frirl_reward_desc), sizeof(struct frirl_desc),'
+                   'offsetof(struct frirl_desc,fiverb), offsetof(struct frirl_desc,fus_is_rule_inserted));return 0;}\n')
+    exe = tmp_path / "lay"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in got] == [280, 96, 152, 176, 208, 276, 64, 32, 24, 472, 264, 400]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "examples")), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("env", ["mountaincar", "cartpole", "acrobot"])
+def test_reference_examples_compile_and_link_unchanged(env, built, tmp_path):
+    exe = tmp_path / env
+    cmd = ["gcc", "-O2", "-w", "-I", os.path.join(ROOT, "include"), os.path.join(REF, "examples", env, env + ".c"), "-o", str(exe),
+           "-L", LIBDIR, "-lfrirl_dropin", "-lfrirl_hip", "-Wl,-rpath," + LIBDIR, "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    und = subprocess.run(["nm", "-u", str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "frirl_run" in und and "frirl_init" in und
+
+
+def load_rb(path):
+    return np.loadtxt(path, dtype=np.float64, ndmin=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,steps_rules", [("mountaincar", 110), ("cartpole", 182), ("acrobot", 367)])
+def test_demo_parity_through_dropin_api(env, steps_rules, built, tmp_path, golden_dir):
+    """test_ALL.sh equivalent (reference tests/_test.sh:1-17 diffs the rule-base text dump), non-interactive.
+    Same rule count, same antecedents in the same order (bit-exact), Q within 1e-6 relative of the
+    reference compiled in the build container (host callbacks use glibc trig exactly like the reference)."""
+    lib, demo = built
+    r = subprocess.run([demo, "--env", env, "-q"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "converged 1" in r.stdout
+    mine = load_rb(tmp_path / f"{env}.frirlrb.txt")
+    ref = load_rb(os.path.join(golden_dir, f"ref_{env}.frirlrb.txt"))
+    assert mine.shape == ref.shape and mine.shape[0] == steps_rules
+    assert (mine[:, :-1] == ref[:, :-1]).all(), "antecedents / rule order differ from the reference"
+    rel = np.abs(mine[:, -1] - ref[:, -1]) / np.maximum(np.abs(ref[:, -1]), 1e-9)
+    assert rel.max() <= 1e-6, rel.max()
+    orig = load_rb(os.path.join(golden_dir, "orig", f"frirl_example_{env}.frirlrb.txt"))
+    assert (mine[:, :-1] == orig[:, :-1]).all(), "antecedents differ from the reference's shipped golden file"
+    if env != "acrobot":        # acrobot's shipped Q column is libm-era dependent
+        relo = np.abs(mine[:, -1] - orig[:, -1]) / np.maximum(np.abs(orig[:, -1]), 1e-9)
+        assert relo.max() <= 1e-6
+    # binary dump: int count + (nant + 1) doubles per rule (reference frirl_utils.c:175-203)
+    raw = (tmp_path / f"{env}.frirlrb.bin").read_bytes()
+    n = int(np.frombuffer(raw[:4], dtype=np.int32)[0])
+    assert n == mine.shape[0] and len(raw) == 4 + n * mine.shape[1] * 8
+    body = np.frombuffer(raw[4:], dtype=np.float64).reshape(n, mine.shape[1])
+    assert np.allclose(body, mine, rtol=0, atol=1e-15 * np.abs(mine).max() + 1e-18) or (np.abs(body - mine) <= 5e-19 + 1e-15 * np.abs(mine)).all()
