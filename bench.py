@@ -6,10 +6,14 @@
 
 One "step" = one pass of the hot path over one batch: five_hip_rule_distance over E independent
 rule bases of R rules each (E*R rule-distance evaluations, distances materialised as the reference's
-five_rule_distance does).  Default workload = BASELINE.json configs[1]: mountaincar-shaped
-(nant 3, U 41), 8192 rules x 8192 environments per GPU.  Environments are sharded over ranks with
-no data-path collective (weak scaling); value = all ranks' evaluations / max-over-ranks time.
-Inputs are synthetic, generated on the device and resident in HBM before the timed region.
+five_rule_distance does) -- BASELINE.json's metric "rule-distance evals/sec (rules x envs)".  The second
+half of that metric, env-steps/sec, is measured by a second timed leg (fused do_action + reward +
+quantise + greedy sweep + SARSA update per environment) and reported under "env_steps".
+Default workload = BASELINE.json configs[1]: mountaincar (nant 3, U 41, real tables and dynamics),
+8192 rules x 8192 environments per GPU.  Environments are sharded over ranks by env id with no
+data-path collective (weak scaling); only the per-episode reward statistics are all-reduced (RCCL).
+value = all ranks' evaluations / max-over-ranks time.  Inputs are synthetic, generated on the device
+and resident in HBM before the timed region.
 """
 import argparse
 import json
@@ -24,23 +28,20 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
-WORKLOADS = {   # name -> nant, U, R, E(per GPU), A
-    "cfg2_mountaincar_8k_x_8k": dict(nant=3, U=41, R=8192, E=8192, A=3),
-    "cfg3_cartpole_32k_x_32k": dict(nant=5, U=1001, R=32768, E=32768, A=21),
-    "cfg4_acrobot_64k_x_8k_per_gpu": dict(nant=5, U=41, R=65536, E=8192, A=3),
-    "cfg5_synth16_256k": dict(nant=16, U=1001, R=262144, E=64, A=0),
+WORKLOADS = {   # name -> demo env (tables / grids / dynamics), nant, U, R (rules per env), E (envs per GPU), A
+    "cfg2_mountaincar_8k_x_8k": dict(env="mountaincar", nant=3, U=41, R=8192, E=8192, A=3),
+    "cfg3_cartpole_32k_x_32k": dict(env="cartpole", nant=5, U=1001, R=32768, E=32768, A=21),
+    "cfg4_acrobot_64k_x_8k_per_gpu": dict(env="acrobot", nant=5, U=41, R=65536, E=8192, A=3),
+    "cfg5_synth16_256k": dict(env=None, nant=16, U=1001, R=262144, E=64, A=0),
 }
 
 
 def synth_problem(w, device, seed):
-    """SURVEY 8d synthetic inputs, generated on the device: shared universes / VE tables, one private rule
-    base per environment with on-grid antecedents (uniform universe indices; the action column uses the A
-    action grid points when A > 0) and Q ~ U(-1500, 1500).  Duplicates are not removed (they only matter
-    for exact-hit tie-breaking, which is defined: lowest index)."""
+    """cfg5 (no environment): synthetic universes / VE tables and on-grid rule bases generated on the device."""
     import numpy as np
     import torch
     import frirl_amd
-    nant, U, R, E, A = w["nant"], w["U"], w["R"], w["E"], w["A"]
+    nant, U, R, E = w["nant"], w["U"], w["R"], w["E"]
     g = torch.Generator(device=device).manual_seed(0x5EED0000 + seed)
     rng = np.random.default_rng(1234)
     u = np.zeros((nant, U))
@@ -48,33 +49,24 @@ def synth_problem(w, device, seed):
     for k in range(nant):
         div = 2.0 * (k + 1) / (U - 1)
         half = [-(U - 1) * div / 2 + div * i for i in range(U // 2 + 1)]
-        row = half + [-half[U - 1 - i] for i in range(U // 2 + 1, U)]
-        u[k] = row
+        u[k] = half + [-half[U - 1 - i] for i in range(U // 2 + 1, U)]
         scf = 0.5 + rng.random(U)
         ve[k, 1:] = np.cumsum((u[k, 1:] - u[k, :-1]) * (scf[:-1] + scf[1:]) * 0.5)
     u_d, ve_d = torch.from_numpy(u).to(device), torch.from_numpy(ve).to(device)
     rb = torch.empty((E, nant + 1, R), dtype=torch.float64, device=device)
     for k in range(nant):
-        if A > 0 and k == nant - 1:
-            idx = (torch.randint(0, A, (E, R), generator=g, device=device) * (U - 1)) // max(A - 1, 1)
-        else:
-            idx = torch.randint(0, U, (E, R), generator=g, device=device)
-        rb[:, k, :] = ve_d[k][idx]
-        del idx
+        rb[:, k, :] = ve_d[k][torch.randint(0, U, (E, R), generator=g, device=device)]
     rb[:, nant, :] = torch.rand((E, R), generator=g, device=device, dtype=torch.float64) * 3000.0 - 1500.0
     nrules = torch.full((E,), R, dtype=torch.int32, device=device)
-    prob = frirl_amd.Problem(u_d, ve_d, rb, nrules)
-    lo = u_d[:, 0]
-    hi = u_d[:, U - 2]
-    x = (lo + (hi - lo) * torch.rand((E, nant), generator=g, device=device, dtype=torch.float64)).contiguous()
-    # 1 % exact grid hits to exercise the index path
-    nh = max(1, E // 100)
-    pick = torch.randint(0, R, (nh,), generator=g, device=device)
-    for j in range(nh):
-        vals = rb[j, :nant, pick[j]]
-        # invert ve -> u exactly: the VE tables are strictly increasing
-        x[j] = torch.stack([u_d[k][torch.searchsorted(ve_d[k], vals[k])] for k in range(nant)])
-    return prob, x
+    return frirl_amd.Problem(u_d, ve_d, rb, nrules), None, None
+
+
+def make_queries(prob, device, seed):
+    """Observations for the distance sweep: continuous, uniform over each universe (snapped by the kernel)."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(77 + seed)
+    lo, hi = prob.u[:, 0], prob.u[:, prob.U - 2]
+    return (lo + (hi - lo) * torch.rand((prob.E, prob.nant), generator=g, device=device, dtype=torch.float64)).contiguous()
 
 
 def cpu_baseline(w):
@@ -115,6 +107,8 @@ def main():
     ap.add_argument("--workload", default="cfg2_mountaincar_8k_x_8k", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="override environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--env-steps", type=int, default=20, help="timed environment steps of the fused SARSA leg")
+    ap.add_argument("--no-env-steps", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -131,43 +125,65 @@ def main():
         dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    frirl_amd.build()
+    if not (os.path.exists(frirl_amd.HIP_LIB_PATH) and os.path.exists(frirl_amd.DROPIN_LIB_PATH)):
+        frirl_amd.build()          # normally prebuilt by __graft_entry__.build(); never rebuilt per rank
+    D = frirl_amd.dist()
     w = dict(WORKLOADS[args.workload])
     if args.envs:
         w["E"] = args.envs
-    prob, x = synth_problem(w, device, seed=rank)
     E, R, nant = w["E"], w["R"], w["nant"]
+    env_start, _ = D.shard(E * world, world, rank)            # this rank's slice of the global env ids
+    if w["env"]:
+        maxR = R + 256                                        # head-room: the SARSA leg appends rules
+        prob, agent, envs = frirl_amd.demo_batch(w["env"], E, R, maxR, device, seed=env_start)
+    else:
+        prob, agent, envs = synth_problem(w, device, seed=env_start)
+    x = make_queries(prob, device, seed=env_start)
     dists = torch.empty((E, prob.maxR), dtype=torch.float64, device=device)
     hit = torch.empty((E,), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream()
 
-    def step():
-        prob.rule_distance(x, ruledists=dists, hit=hit, stream=stream)
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        sync_all()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # on the launch stream
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(steps):
+            fn()
+        ev1.record(stream)
+        sync_all()
+        dt = time.perf_counter() - t0
+        return D.max_over_ranks(dt, device), ev0.elapsed_time(ev1) / steps
+
+    # ---- leg 1 (the metric): rule-distance sweep, distances materialised ---------------------------------
+    dt, kern_ms = timed(lambda: prob.rule_distance(x, ruledists=dists, hit=hit, stream=stream), args.steps, args.warmup)
+    nhits = torch.tensor([float((hit >= 0).sum().item())], dtype=torch.float64, device=device)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # same stream as the launches
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps            # average launch duration incl. the 4*E-byte hit memset
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    stats = torch.tensor([float((hit >= 0).sum().item()), float(E)], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)        # statistics only; no data-path collective
-    dt = float(tmax.item())
+        dist.all_reduce(nhits)
+
+    # ---- leg 2: whole environment steps (do_action, reward, quantise, greedy sweep, SARSA update) ---------
+    env_leg = None
+    if agent is not None and not args.no_env_steps:
+        frirl_amd.episode_begin(prob, agent, envs, stream=stream)
+        edt, ems = timed(lambda: frirl_amd.episode_step(prob, agent, envs, stream=stream), args.env_steps, min(args.warmup, 3))
+        # per-episode reward statistics: the ONLY cross-rank exchange (RCCL all-reduce over xGMI when N > 1)
+        st = D.allreduce_stats(envs.ep_reward, envs.ep_steps, envs.done, prob.nrules)
+        status = torch.bincount(envs.status.long(), minlength=6).tolist()
+        env_leg = {"value": float(E) * world * args.env_steps / edt, "unit": "env-steps/s", "steps": args.env_steps,
+                   "ms_per_step": edt / args.env_steps * 1e3, "avg_launch_ms": ems,
+                   "algorithmic_bytes_per_step": float(E) * (2.0 * R * (nant + 1) * 8 + R * 8),
+                   "stats_allreduce": {"envs": st.envs, "mean_reward": st.mean_reward, "mean_rules": st.mean_rules, "steps_sum": st.steps_sum,
+                                       "episodes_done": st.success, "reward_min": st.reward_min, "reward_max": st.reward_max},
+                   "last_step_outcomes_rank0": dict(zip(["inactive", "exact", "spread", "inserted", "skipped", "full"], status))}
+        env_leg["effective_GBps"] = env_leg["algorithmic_bytes_per_step"] / (ems * 1e-3) / 1e9
 
     if rank == 0:
         evals = float(E) * R * args.steps * world
@@ -178,11 +194,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "nant": nant, "universe_len": w["U"], "rules_per_env": R, "envs_per_gpu": E,
-                       "sharding": f"envs x{world}, no data-path collective", "exact_hits": int(stats[0].item())},
+                       "sharding": f"env ids split over {world} rank(s), no data-path collective; reward statistics all-reduced",
+                       "exact_hits": int(nhits.item())},
             "roofline": {"bound": "hbm", "kernel": "rule_distance_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_ms},
         }
+        if env_leg:
+            out["env_steps"] = env_leg
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
             if tr and not args.envs:

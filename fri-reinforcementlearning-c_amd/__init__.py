@@ -256,3 +256,99 @@ def episode_begin(problem, agent, envs, stream=None):
 def episode_step(problem, agent, envs, stream=None):
     check(lib().frirl_hip_episode_step(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc),
                                        _stream(stream)), "frirl_hip_episode_step")
+
+
+def dist():
+    """The multi-GPU helper module (fri-reinforcementlearning-c_amd/dist.py)."""
+    import importlib.util
+    import sys
+    if "frirl_amd_dist" in sys.modules:
+        return sys.modules["frirl_amd_dist"]
+    spec = importlib.util.spec_from_file_location("frirl_amd_dist", os.path.join(PKG_DIR, "dist.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["frirl_amd_dist"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+DROPIN_LIB_PATH = os.path.join(PKG_DIR, "lib", "libfrirl_dropin.so")
+_dropin = None
+
+
+def dropin():
+    """ctypes handle of the ANSI-C drop-in library (the reference's five_* / FIVE_* / frirl_* API)."""
+    global _dropin
+    if _dropin is None:
+        lib()                                   # loads torch's HIP runtime + libfrirl_hip.so first
+        if not os.path.exists(DROPIN_LIB_PATH):
+            raise FrirlHipError(f"{DROPIN_LIB_PATH} is missing: run build() first")
+        D = C.CDLL(DROPIN_LIB_PATH)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        D.frirl_demo_describe.restype = C.c_int
+        D.frirl_demo_describe.argtypes = [C.c_char_p, ip, ip, ip, dp, dp, dp, ip, dp, dp, dp, dp, ip]
+        _dropin = D
+    return _dropin
+
+
+def demo_describe(env):
+    """Tables, grids and hyper-parameters of a demo, built by the drop-in library's own host functions
+    (frirl_init_ve etc.); no GPU needed."""
+    import numpy as np
+    D = dropin()
+    ns, U, A, ms = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if D.frirl_demo_describe(env.encode(), C.byref(ns), C.byref(U), C.byref(A), None, None, None, None, None, None, None, None, C.byref(ms)) != 0:
+        raise ValueError(f"unknown demo environment {env!r}")
+    nant = ns.value + 1
+    u, ve = np.zeros((nant, U.value)), np.zeros((nant, U.value))
+    grid = np.zeros((nant, MAX_GRID))
+    grid_len = np.zeros(nant, dtype=np.int32)
+    grid_div, values_def = np.zeros(nant), np.zeros(nant)
+    action_ve, hp = np.zeros(A.value), np.zeros(8)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    rc = D.frirl_demo_describe(env.encode(), C.byref(ns), C.byref(U), C.byref(A), u.ctypes.data_as(dp), ve.ctypes.data_as(dp),
+                               grid.ctypes.data_as(dp), grid_len.ctypes.data_as(ip), grid_div.ctypes.data_as(dp),
+                               values_def.ctypes.data_as(dp), action_ve.ctypes.data_as(dp), hp.ctypes.data_as(dp), C.byref(ms))
+    assert rc == 0
+    return dict(env=env, kind=ENV_KINDS[env], nstates=ns.value, nant=nant, U=U.value, A=A.value, u=u, ve=ve,
+                grids=[grid[k, : grid_len[k]].copy() for k in range(nant)], grid_div=grid_div, values_def=values_def, action_ve=action_ve,
+                alpha=hp[0], gamma=hp[1], qdiff_pos=hp[2], qdiff_neg=hp[3], weight_thr=hp[4], skip_rules=int(hp[5]),
+                reward_good_above=hp[6], qdiff_final_tolerance=hp[7], max_steps=ms.value)
+
+
+def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None):
+    """E environments of a demo on `device`, each with a private synthetic rule base of R rules: the 2^nant
+    corner rules first (reference frirl_init_rb.c:99-126, Q = 0), then rules on the universe grid (uniform
+    indices; action column on the A action values) with Q ~ U(-1500, 1500).
+    Returns (Problem, Agent, Envs)."""
+    import numpy as np
+    import torch
+    d = demo_describe(env)
+    nant, U, A = d["nant"], d["U"], d["A"]
+    assert maxR >= R and maxR % 2 == 0 and R >= 2 ** nant
+    g = torch.Generator(device=device).manual_seed(0x5EED0000 + seed)
+    u_d, ve_d = torch.from_numpy(d["u"]).to(device), torch.from_numpy(d["ve"]).to(device)
+    rb = torch.zeros((E, nant + 1, maxR), dtype=torch.float64, device=device)
+    rant = torch.zeros((E, nant, maxR), dtype=torch.float64, device=device)
+    ncorner = 2 ** nant
+    # action universe index of every action value (nearest universe point, as FIVE_add_rule snaps it)
+    ua = d["u"][nant - 1]
+    a_idx = torch.tensor([int(np.argmin(np.abs(ua - v))) for v in d["grids"][nant - 1]], device=device)
+    for k in range(nant):
+        idx = torch.randint(0, U, (E, R), generator=g, device=device)
+        if k == nant - 1:
+            idx = a_idx[torch.randint(0, A, (E, R), generator=g, device=device)]
+        gk = d["grids"][k]
+        lo_i, hi_i = int(np.argmin(np.abs(d["u"][k] - gk.min()))), int(np.argmin(np.abs(d["u"][k] - gk.max())))
+        divider = ncorner >> (k + 1)
+        corner = torch.tensor([lo_i if ((j // divider) % 2) == 0 else hi_i for j in range(ncorner)], device=device)
+        idx[:, :ncorner] = corner[None]
+        rb[:, k, :R] = ve_d[k][idx]
+        rant[:, k, :R] = u_d[k][idx]
+        del idx
+    rb[:, nant, ncorner:R] = torch.rand((E, R - ncorner), generator=g, device=device, dtype=torch.float64) * 3000.0 - 1500.0
+    nrules = torch.full((E,), R, dtype=torch.int32, device=device)
+    prob = Problem(u_d, ve_d, rb, nrules)
+    agent = Agent(device, nant, d["grids"], d["grid_div"], d["values_def"], d["action_ve"], d["alpha"], d["gamma"], d["qdiff_pos"],
+                  d["qdiff_neg"], d["weight_thr"], d["skip_rules"], 0, d["kind"], max_steps or d["max_steps"])
+    envs = Envs(prob, device, rant_init=rant)
+    return prob, agent, envs

@@ -67,7 +67,7 @@ HOST_CFLAGS = ["-O2", "-std=gnu99", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno
 
 def build_host(force=False, verbose=False):
     """libfrirl_dropin.so: the reference's five_* / FIVE_* / frirl_* C API on top of libfrirl_hip.so; + the demo driver."""
-    srcs = [os.path.join(HOST_DIR, f) for f in ("five_host.c", "frirl_host.c", "frirl_io.c")]
+    srcs = [os.path.join(HOST_DIR, f) for f in ("five_host.c", "frirl_host.c", "frirl_io.c", "demo_envs.c")]
     deps = srcs + glob.glob(os.path.join(HOST_DIR, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + [HIP_LIB]
     inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST_DIR]
     if force or _stale(DROPIN_LIB, deps):

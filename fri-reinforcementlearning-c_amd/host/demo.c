@@ -1,14 +1,12 @@
 /*
  * demo.c -- the three demo applications driven through the drop-in C API (one binary, --env NAME).
  *
- * Own driver for machines without the reference tree (the GPU box): it fills struct frirl_desc with the
- * hyper-parameters of the reference's examples (data from examples/<env>/<env>.c main()), installs host
- * callbacks implementing the same dynamics with libm trig, calls frirl_init / frirl_run (construct mode)
- * and dumps <env>.frirlrb.txt/.bin exactly like the reference's examples.  The reference's own,
- * unchanged example sources also compile and link against these headers and this library.
+ * Own driver for machines without the reference tree (the GPU box): frirl_demo_setup() (demo_envs.c) fills
+ * struct frirl_desc with the hyper-parameters of the reference's examples and host callbacks implementing
+ * the same dynamics with libm trig; then frirl_init / frirl_run (construct mode) and the <env>.frirlrb.txt/.bin
+ * dumps, exactly the sequence of the reference's examples.  The reference's own, unchanged example
+ * sources also compile and link against these headers and this library.
  */
-#define _GNU_SOURCE
-#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,139 +14,15 @@
 #include "frirl.h"
 #include "frirl_types_def.h"
 #include "frirl_app_helpers.h"
-
-#define PI 3.14159265358979323846264338327
-
-static void generic_quantize(struct frirl_desc *fr, fri_float *s, int n, fri_float *q)
-{
-    int i;
-    for (i = 0; i < n; i++) {
-        int where = (int)round((s[i] + fabs(fr->statedims[i].values[0])) / fr->statedims[i].values_div);
-        if (where < 0) where = 0;
-        else if (where > fr->statedims[i].values_len - 1) where = fr->statedims[i].values_len - 1;
-        q[i] = fr->statedims[i].values[where];
-    }
-}
-
-/* mountain car */
-static void mc_do_action(struct frirl_desc *fr, fri_float a, fri_float *s, int n, fri_float *ns)
-{
-    double v = (s[1] + (0.001 * a) + (-0.0025 * cos(3.0 * s[0]))) * 0.999, p;
-    (void)fr; (void)n;
-    if (v < -0.07) v = -0.07;
-    if (v > 0.07) v = 0.07;
-    p = s[0] + v;
-    if (p <= -1.5) { p = -1.5; v = 0.0; }
-    ns[0] = p; ns[1] = v;
-}
-static void mc_reward(struct frirl_desc *fr, fri_float *s, int n, struct frirl_reward_desc *rw)
-{
-    (void)fr; (void)n;
-    rw->value = -10; rw->success = 0;
-    if (s[0] >= 0.45) { rw->value = 1000; rw->success = 1; }
-}
-
-/* cart pole (sin and cos of the same angle through one sincos(), as gcc -O2 compiles the reference) */
-static void cp_do_action(struct frirl_desc *fr, fri_float a, fri_float *s, int n, fri_float *ns)
-{
-    const double g = 9.8, mt = 1.0 + 0.1, mp = 0.1, len = 0.5, pml = mp * len, tau = 0.02, fourthirds = 4.0 / 3.0;
-    const double force = a * 10.0;
-    double sn, cs, temp, thacc, xacc;
-    (void)fr; (void)n;
-    sincos(s[2], &sn, &cs);
-    temp = (force + pml * s[3] * s[3] * sn) / mt;
-    thacc = (g * sn - cs * temp) / (len * (fourthirds - mp * cs * cs / mt));
-    xacc = temp - pml * thacc * cs / mt;
-    ns[0] = s[0] + tau * s[1];
-    ns[1] = s[1] + tau * xacc;
-    ns[2] = s[2] + tau * s[3];
-    ns[3] = s[3] + tau * thacc;
-}
-static void cp_reward(struct frirl_desc *fr, fri_float *s, int n, struct frirl_reward_desc *rw)
-{
-    const double lim = PI / 4;
-    (void)fr; (void)n;
-    if (s[0] < -4.0 || s[0] > 4.0 || s[2] < (-1 * lim) || s[2] > lim) { rw->value = -10000 - 50 * fabs(s[0]) - 100 * fabs(s[2]); rw->success = 1; }
-    else { rw->value = 10 - 1000 * s[2] * s[2] - 5 * fabs(s[0]) - 10 * s[3]; rw->success = 0; }
-}
-static void cp_quantize(struct frirl_desc *fr, fri_float *s, int n, fri_float *q)
-{
-    const double d12 = PI / 15, d3 = PI / 60;
-    double q0 = s[0], q1 = round(s[1]), q2 = floor(s[2] / d3) * d3, q3 = s[3];
-    (void)fr; (void)n;
-    if (q0 < 0) q0 = -1;
-    if (q0 > 0) q0 = 1;
-    if (q1 < -1) q1 = -1;
-    if (q1 > 1) q1 = 1;
-    if (q2 > d12) q2 = d12;
-    if (q2 < (-1 * d12)) q2 = -1 * d12;
-    if (q3 < 0) q3 = -1;
-    if (q3 > 0) q3 = 1;
-    q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
-}
-
-/* acrobot */
-static void ab_do_action(struct frirl_desc *fr, fri_float torque, fri_float *s, int n, fri_float *ns)
-{
-    const double vmax1 = 4 * PI, vmax2 = 9 * PI, m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8, dt = 0.05;
-    const double l1sq = l1 * l1, lc1sq = lc1 * lc1, lc2sq = lc2 * lc2;
-    double t1 = s[0], t2 = s[1], t1d = s[2], t2d = s[3];
-    double c2, s2, d1, d2, phi1, phi2, acc1, acc2;
-    int i;
-    (void)fr; (void)n;
-    sincos(t2, &s2, &c2);
-    d1 = m1 * lc1sq + m2 * (l1sq + lc2sq + 2 * l1 * lc2 * c2) + I1 + I2;
-    d2 = m2 * (lc2sq + l1 * lc2 * c2) + I2;
-    phi2 = m2 * lc2 * g * cos(t1 + t2 - PI / 2);
-    phi1 = -m2 * l1 * lc2 * t2d * s2 * (t2d - 2 * t1d) + (m1 * lc1 + m2 * l1) * g * cos(t1 - (PI / 2)) + phi2;
-    acc2 = (torque + phi1 * (d2 / d1) - m2 * l1 * lc2 * t1d * t1d * s2 - phi2);
-    acc2 = acc2 / (m2 * lc2sq + I2 - (d2 * d2 / d1));
-    acc1 = -(d2 * acc2 + phi1) / d1;
-    for (i = 0; i < 4; i++) {
-        t1d = t1d + acc1 * dt;
-        if (t1d < -vmax1) t1d = -vmax1;
-        if (t1d > vmax1) t1d = vmax1;
-        t1 = t1 + t1d * dt;
-        t2d = t2d + acc2 * dt;
-        if (t2d < -vmax2) t2d = -vmax2;
-        if (t2d > vmax2) t2d = vmax2;
-        t2 = t2 + t2d * dt;
-    }
-    if (t1 < -PI) t1 = -PI;
-    if (t1 > PI) t1 = PI;
-    if (t2 < -PI) t2 = -PI;
-    if (t2 > PI) t2 = PI;
-    ns[0] = t1; ns[1] = t2; ns[2] = t1d; ns[3] = t2d;
-}
-static void ab_reward(struct frirl_desc *fr, fri_float *s, int n, struct frirl_reward_desc *rw)
-{
-    const double y1 = 0.0 - cos(s[0]);
-    const double y2 = y1 - cos(s[1]);
-    (void)fr; (void)n;
-    rw->value = -10; rw->success = 0;
-    if (y2 >= 0.0 + 1.0) { rw->value = 1000; rw->success = 1; }
-}
-
-static void set_dim(struct frirl_dimension_desc *d, int n, const double *vals, double *store, double vdiv, double steep, double def, int U, double udiv)
-{
-    memset(d, 0, sizeof *d);
-    d->values_len = n; d->values = store; d->values_div = vdiv; d->values_steep = steep; d->values_def = def;
-    d->universe_len = U; d->universe_div = udiv;
-    d->universe = malloc(sizeof(double) * U);
-    if (vals) memcpy(store, vals, sizeof(double) * n); else frirl_gen_fixres_arr(store, n, vdiv);
-    frirl_gen_fixres_arr(d->universe, U, udiv);
-}
+#include "frirl_demo.h"
 
 int main(int argc, char **argv)
 {
     struct frirl_desc fr = frirl_desc_default;
-    static struct frirl_dimension_desc sd[4];
-    static double v[5][32];
     const char *env = "mountaincar";
     char name[128];
-    int i, max_episodes = 0;
+    int i, max_episodes = 0, fargc = 0;
     char *fargv[16];
-    int fargc = 0;
     fargv[fargc++] = argv[0];
     for (i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--env") && i + 1 < argc) env = argv[++i];
@@ -156,48 +30,7 @@ int main(int argc, char **argv)
         else if (fargc < 15) fargv[fargc++] = argv[i];
     }
     frirl_parse_cmdline(&fr, fargc, fargv);
-    fr.skip_rules = 1;
-    if (!strcmp(env, "mountaincar")) {
-        static const double v0[] = {-1.5, -1.295, -1.09, -0.885, -0.68, -0.475, -0.27, -0.065, 0.14, 0.345};
-        static const double v1[] = {-0.07, -0.042, -0.014, 0.014, 0.042, 0.07};
-        fr.reward_good_above = -5000.0; fr.alpha = 0.5; fr.gamma = 1.0; fr.epsilon = 0.01;
-        fr.qdiff_pos_boundary = 1.0; fr.qdiff_neg_boundary = -4.0; fr.qdiff_final_tolerance = 500.0;
-        fr.do_action_func = mc_do_action; fr.get_reward_func = mc_reward; fr.quant_obs_func = generic_quantize;
-        set_dim(&sd[0], 10, v0, v[0], 0.205, 1.0, -0.5, 41, 0.1);
-        set_dim(&sd[1], 6, v1, v[1], 0.028, 1.0, 0.0, 41, 0.005);
-        fr.statedims_len = 2;
-        set_dim(&fr.actiondim, 3, NULL, v[4], 1.0, 0.0, 0.0, 41, 0.1);
-    } else if (!strcmp(env, "cartpole")) {
-        static const double v2[] = {-0.2094, -0.1571, -0.1047, -0.0524, 0.0, 0.0524, 0.1047, 0.1571, 0.2094};
-        static const double va[] = {-1.0, -0.9, -0.8, -0.7, -0.6, -0.5, -0.3999999999999999, -0.29999999999999992, -0.19999999999999995,
-                                    -0.09999999999999998, 0.0, +0.09999999999999998, +0.19999999999999995, +0.29999999999999992,
-                                    +0.3999999999999999, +0.5, +0.6, +0.7, +0.8, +0.9, +1.0};
-        fr.reward_good_above = 0.0; fr.alpha = 0.3; fr.gamma = 1.0; fr.epsilon = 0.001;
-        fr.qdiff_pos_boundary = 1.0; fr.qdiff_neg_boundary = -200.0; fr.qdiff_final_tolerance = 250.0;
-        fr.do_action_func = cp_do_action; fr.get_reward_func = cp_reward; fr.quant_obs_func = cp_quantize;
-        set_dim(&sd[0], 2, NULL, v[0], 2.0, 1.0, 1.0, 1001, 0.016);
-        set_dim(&sd[1], 3, NULL, v[1], 1.0, 1.0, 0.0, 1001, 0.032);
-        set_dim(&sd[2], 9, v2, v[2], 0.0524, 21.485917317405871, 0.0, 1001, 0.0031415926535897933);
-        set_dim(&sd[3], 2, NULL, v[3], 2.0, 1.0, 0.0, 1001, 0.016);
-        fr.statedims_len = 4;
-        set_dim(&fr.actiondim, 21, va, v[4], 0.1, 0.0, 0.0, 1001, 0.008);
-    } else if (!strcmp(env, "acrobot")) {
-        static const double v0[] = {-1.570796326794897, -0.785398163397448, 0, 0.785398163397448, 1.570796326794897};
-        fr.reward_good_above = 0.0; fr.alpha = 0.5; fr.gamma = 1.0; fr.epsilon = 0.001;
-        fr.qdiff_pos_boundary = 1.0; fr.qdiff_neg_boundary = -200.0; fr.qdiff_final_tolerance = 50.0;
-        fr.do_action_func = ab_do_action; fr.get_reward_func = ab_reward; fr.quant_obs_func = generic_quantize;
-        set_dim(&sd[0], 5, v0, v[0], 0.785398163397448, 1.0, 0.0, 41, 0.1);
-        set_dim(&sd[1], 5, v0, v[1], 0.785398163397448, 1.0, 0.0, 41, 0.1);
-        set_dim(&sd[2], 3, NULL, v[2], 0.785398163397448, 1.0, 0.0, 41, 0.05);
-        set_dim(&sd[3], 3, NULL, v[3], 0.785398163397448, 1.0, 0.0, 41, 0.05);
-        fr.statedims_len = 4;
-        set_dim(&fr.actiondim, 3, NULL, v[4], 1.0, 0.0, 0.0, 41, 0.1);
-    } else {
-        fprintf(stderr, "unknown --env %s (mountaincar|cartpole|acrobot)\n", env);
-        return 2;
-    }
-    fr.statedims = sd;
-    fr.construct_rb = 1;                 /* construct mode (the reference's mountaincar ships reduce-only) */
+    if (frirl_demo_setup(&fr, env) != 0) return 2;
     if (max_episodes > 0) fr.max_episodes = max_episodes;
     if (frirl_init(&fr) != 0) { fprintf(stderr, "frirl_init failed\n"); return 1; }
     frirl_run(&fr, 1);
@@ -206,8 +39,7 @@ int main(int argc, char **argv)
     snprintf(name, sizeof name, "%s.frirlrb.txt", env);
     frirl_save_rb_to_text_file(&fr, name);
     printf("demo %s: episodes %u steps(last) %d rules %d converged %d\n", env, fr.episode_num, fr.reward.ep_total_steps, fr.fiverb->numofrules, fr.epended);
-    for (i = 0; i < fr.statedims_len; i++) free(sd[i].universe);
-    free(fr.actiondim.universe);
     frirl_deinit(&fr);
+    frirl_demo_release(&fr);
     return 0;
 }

@@ -1,0 +1,17 @@
+/*
+ * frirl_demo.h -- the three demo environments of the reference (examples/mountaincar, cartpole, acrobot)
+ * packaged in the drop-in library: descriptors + host callbacks, so that drivers and bindings on machines
+ * without the reference tree can run them.  Additive API (not in the reference).
+ */
+#ifndef FRIRL_DEMO_H
+#define FRIRL_DEMO_H
+
+#include "frirl_types.h"
+
+int frirl_demo_setup(struct frirl_desc *fr, const char *env);     /* "mountaincar" | "cartpole" | "acrobot" */
+void frirl_demo_release(struct frirl_desc *fr);
+/* flat description for bindings; u/ve [ (nstates+1) * U ], grid [ (nstates+1) * 64 ]; pass u = ve = NULL to query sizes */
+int frirl_demo_describe(const char *env, int *nstates, int *U, int *A, double *u, double *ve, double *grid, int *grid_len,
+                        double *grid_div, double *values_def, double *action_ve, double *hparams, int *max_steps);
+
+#endif

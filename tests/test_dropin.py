@@ -101,3 +101,24 @@ def test_demo_parity_through_dropin_api(env, steps_rules, built, tmp_path, golde
     assert n == mine.shape[0] and len(raw) == 4 + n * mine.shape[1] * 8
     body = np.frombuffer(raw[4:], dtype=np.float64).reshape(n, mine.shape[1])
     assert np.allclose(body, mine, rtol=0, atol=1e-15 * np.abs(mine).max() + 1e-18) or (np.abs(body - mine) <= 5e-19 + 1e-15 * np.abs(mine)).all()
+
+
+@pytest.mark.parametrize("env", ["mountaincar", "cartpole", "acrobot"])
+def test_demo_tables_bit_exact_vs_oracle(env, built):
+    """Universes, VE tables, per-action VE values, grids and hyper-parameters produced by the drop-in library's
+    host functions (frirl_init_ve, FIVE_GSc_func, FIVEGVagEnv, frirl_gen_fixres_arr) == the oracle's, bit for bit
+    (the oracle's are pinned against the genuine reference in test_oracle_golden.py).  Host-only, no GPU."""
+    from oracle import binding as ob
+    d = frirl_amd.demo_describe(env)
+    fr = ob.Frirl(env)
+    f = fr.five
+    assert (d["nant"], d["U"], d["A"]) == (f.nant, f.U, fr.nactions)
+    assert (d["u"].view(np.uint64) == np.array(f.u).view(np.uint64)).all()
+    assert (d["ve"].view(np.uint64) == np.array(f.ve).view(np.uint64)).all()
+    assert (d["action_ve"].view(np.uint64) == np.array(fr.action_vevalues).view(np.uint64)).all()
+    hp = fr.hparams
+    for k in range(f.nant):
+        od = fr.dim(k)
+        assert (d["grids"][k] == od["values"]).all() and d["grid_div"][k] == od["values_div"] and d["values_def"][k] == od["values_def"]
+    assert (d["alpha"], d["gamma"], d["qdiff_pos"], d["qdiff_neg"], d["weight_thr"], d["skip_rules"]) == \
+           (hp["alpha"], hp["gamma"], hp["qdiff_pos"], hp["qdiff_neg"], hp["weight_thr"], hp["skip_rules"])
