@@ -373,11 +373,12 @@ static int run_bench(int argc, char **argv)
     double t0 = now_s();
     for (int q = 0; q < nq; q++) { five_rule_distance(f, qs + q * nant); acc += f->ruledists[q % R]; }
     double t1 = now_s();
-    for (int q = 0; q < nq; q++) { FIVE_vag_concl(f, qs + q * nant, &conc); acc += conc; }
+    int nq2 = nq / 8 > 8 ? nq / 8 : nq;                 /* Shepard leg: 1/8 of the queries keeps the sample bounded */
+    for (int q = 0; q < nq2; q++) { FIVE_vag_concl(f, qs + q * nant, &conc); acc += conc; }
     double t2 = now_s();
     printf("{\"kind\":\"reference\",\"nant\":%d,\"U\":%d,\"R\":%d,\"nq\":%d,\"rule_distance_s\":%.6f,\"rule_distance_evals_per_s\":%.6e,"
            "\"vag_concl_s\":%.6f,\"vag_concl_evals_per_s\":%.6e,\"check\":%.3e}\n", nant, U, R, nq, t1 - t0, (double)R * nq / (t1 - t0),
-           t2 - t1, (double)R * nq / (t2 - t1), acc);
+           t2 - t1, (double)R * nq2 / (t2 - t1), acc);
     return 0;
 }
 
