@@ -53,6 +53,7 @@ class EnvsDesc(C.Structure):
 
 
 _lib = None
+_DP = C.POINTER(C.c_double)
 
 # name -> (restype, argtypes); every symbol include/frirl_hip.h declares
 SIGNATURES = {
@@ -73,6 +74,23 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "frirl_hip_episode_begin": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
     "frirl_hip_episode_step": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
+    "five_hip_bestact": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # single rule base, host pointers (what the ANSI-C drop-in library calls)
+    "five_hip_mirror_create": (C.c_void_p, [C.c_int32, C.c_int32, _DP, _DP, C.c_int32, C.c_int32]),
+    "five_hip_mirror_destroy": (None, [C.c_void_p]),
+    "five_hip_mirror_upload": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(_DP), _DP]),
+    "five_hip_mirror_add_rule": (C.c_int, [C.c_void_p, _DP, C.c_double]),
+    "five_hip_mirror_remove_rule": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "five_hip_mirror_set_rconc": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
+    "five_hip_mirror_get_rconc": (C.c_int, [C.c_void_p, _DP, C.c_int32]),
+    "five_hip_mirror_numofrules": (C.c_int32, [C.c_void_p]),
+    "five_hip_mirror_rule_distance": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(C.c_uint32)]),
+    "five_hip_mirror_vag_concl": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(C.c_uint32)]),
+    "five_hip_mirror_vag_concl_weight": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(C.c_uint32)]),
+    "five_hip_mirror_bestact": (C.c_int, [C.c_void_p, _DP, _DP]),
+    "five_hip_mirror_get_best_action": (C.c_int, [C.c_void_p, _DP, _DP, C.c_int32, _DP, C.POINTER(C.c_uint32)]),
+    "five_hip_mirror_update_sarsa": (C.c_int, [C.c_void_p, C.POINTER(AgentDesc), _DP, C.c_double, _DP, C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_int32), _DP, _DP, _DP]),
 }
 
 
