@@ -23,12 +23,12 @@ def dp(a):
 def test_mirror_matches_oracle(nant, U, R, A):
     L = frirl_amd.lib()
     b = Batch(nant, U, R, 1, A=A, seed=40 + R, ragged=False)
-    f = b.five(0)
     maxR = b.maxR + 6
+    f0 = b.five(0)
+    f = ob.Five(b.u.ravel(), b.ve.ravel(), nant, U, maxR, np.ascontiguousarray(f0.rant[:R]), np.ascontiguousarray(f0.rconc[:R]))
     m = L.five_hip_mirror_create(nant, U, dp(np.ascontiguousarray(b.u.ravel())), dp(np.ascontiguousarray(b.ve.ravel())), maxR, 0)
     assert m, L.frirl_hip_last_error()
     try:
-        rows = (DP * nant)(*[dp(np.ascontiguousarray(f.veval[k, :R])) for k in range(nant)])
         keep = [np.ascontiguousarray(f.veval[k, :R]) for k in range(nant)]
         rows = (DP * nant)(*[dp(a) for a in keep])
         assert L.five_hip_mirror_upload(m, R, rows, dp(np.ascontiguousarray(f.rconc[:R]))) == 0
