@@ -12,11 +12,13 @@
 //   are in flight.  The observation's VE values are looked up once per workgroup and staged in
 //   LDS.  First exact hit: per-lane minimum index -> wave butterfly -> LDS -> one integer
 //   atomicMin per workgroup (deterministic; only taken when a hit exists).
+#include <stdlib.h>
+
 #include "device_common.h"
 
 namespace frirl {
 
-template <int NANT, bool WRITE, int UNROLL>
+template <int NANT, bool WRITE, int UNROLL, int NT>
 __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_kernel(
     const double *__restrict__ u, const double *__restrict__ ve, int U, const double *__restrict__ rb,
     const int32_t *__restrict__ nrules, int maxR, const double *__restrict__ x, double *__restrict__ dists,
@@ -49,7 +51,11 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_kernel(
             const int rr = r + j * STEP;
             if (rr < r_end) {
 #pragma unroll
-                for (int k = 0; k < NANT; k++) v[j][k] = *reinterpret_cast<const double2 *>(base + (size_t)k * maxR + rr);
+                for (int k = 0; k < NANT; k++) {
+                    const double2 *src = reinterpret_cast<const double2 *>(base + (size_t)k * maxR + rr);
+                    if (NT == 1 || NT == 2) { v[j][k].x = __builtin_nontemporal_load(&src->x); v[j][k].y = __builtin_nontemporal_load(&src->y); }
+                    else v[j][k] = *src;
+                }
             }
         }
 #pragma unroll
@@ -70,7 +76,10 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_kernel(
                 double2 d;
                 d.x = __dsqrt_rn(a0);   // IEEE sqrt (vsqrtpd, five_rule_distance.c:211)
                 d.y = __dsqrt_rn(a1);
-                if (WRITE) *reinterpret_cast<double2 *>(out + rr) = d;   // rows are even-sized: rr+1 < maxR
+                if (WRITE) {                                              // rows are even-sized: rr+1 < maxR
+                    if (NT == 1 || NT == 3) { __builtin_nontemporal_store(d.x, out + rr); __builtin_nontemporal_store(d.y, out + rr + 1); }
+                    else *reinterpret_cast<double2 *>(out + rr) = d;
+                }
                 // first exact hit among valid rules (five_rule_distance.c:215-217,241-262)
                 if (d.y == 0.0 && rr + 1 < R) best = min(best, (unsigned)(rr + 1));
                 if (d.x == 0.0) best = min(best, (unsigned)rr);
@@ -81,17 +90,55 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_kernel(
     if (threadIdx.x == 0 && best != FRIRL_HIP_NO_HIT) atomicMin(&hit[e], best);
 }
 
+struct RdTune { int unroll, chunk, nt; };
+static RdTune rd_tune()
+{
+    RdTune t;
+    const char *u = getenv("FRIRL_HIP_RD_UNROLL"), *c = getenv("FRIRL_HIP_RD_CHUNK"), *n = getenv("FRIRL_HIP_RD_NT");
+    t.unroll = u ? atoi(u) : 0;      // 0 = shipped default
+    t.chunk = c ? atoi(c) : 0;       // 0 = shipped default
+    t.nt = n ? atoi(n) : -1;         // -1 = shipped default (non-temporal loads and stores)
+    return t;
+}
+
+template <int NANT, int UNROLL, int NT>
+static void launch_variant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const double *x, double *ruledists, uint32_t *hit,
+                           hipStream_t s, dim3 grid, int rules_per_block)
+{
+    if (ruledists)
+        hipLaunchKernelGGL((rule_distance_kernel<NANT, true, UNROLL, NT>), grid, dim3(FRIRL_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,
+                           b->maxR, x, ruledists, hit, rules_per_block);
+    else
+        hipLaunchKernelGGL((rule_distance_kernel<NANT, false, UNROLL, NT>), grid, dim3(FRIRL_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,
+                           b->maxR, x, ruledists, hit, rules_per_block);
+}
+
+// Shipped configuration (A/B-measured on MI355X, tools/ab_rd.py, profiles/r01_rule_distance_tuning.md):
+// non-temporal loads AND stores (pure stream, nothing is re-read: +5..8 %), 8 independent column sets
+// per lane for nant <= 5 (all loads issued before the first use), 4 for nant <= 8, 2 above.
+template <int NANT>
+struct RdConfig {
+    static constexpr int UNROLL = (NANT <= 5) ? 8 : (NANT <= 8 ? 4 : 2);
+};
+
 template <int NANT>
 static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const double *x, double *ruledists,
                        uint32_t *hit, hipStream_t s, dim3 grid, int rules_per_block)
 {
-    constexpr int UNROLL = (NANT <= 4) ? 4 : (NANT <= 8 ? 2 : 1);
-    if (ruledists)
-        hipLaunchKernelGGL((rule_distance_kernel<NANT, true, UNROLL>), grid, dim3(FRIRL_BLOCK), 0, s, t->u, t->ve, t->U, b->rb,
-                           b->nrules, b->maxR, x, ruledists, hit, rules_per_block);
-    else
-        hipLaunchKernelGGL((rule_distance_kernel<NANT, false, UNROLL>), grid, dim3(FRIRL_BLOCK), 0, s, t->u, t->ve, t->U, b->rb,
-                           b->nrules, b->maxR, x, ruledists, hit, rules_per_block);
+    constexpr int UNROLL = RdConfig<NANT>::UNROLL;
+    const RdTune tn = rd_tune();
+    if (NANT <= 5 && (tn.unroll || tn.nt >= 0)) {      // tuning hooks (experiments only)
+        const int un = tn.unroll ? tn.unroll : UNROLL;
+        const int nt = tn.nt >= 0 ? tn.nt : 1;
+#define V(U_, N_) launch_variant<NANT, U_, N_>(t, b, x, ruledists, hit, s, grid, rules_per_block)
+        if (nt == 1) { if (un == 1) V(1, 1); else if (un == 2) V(2, 1); else if (un == 8) V(8, 1); else V(4, 1); }
+        else if (nt == 2) { if (un == 1) V(1, 2); else if (un == 2) V(2, 2); else if (un == 8) V(8, 2); else V(4, 2); }
+        else if (nt == 3) { if (un == 1) V(1, 3); else if (un == 2) V(2, 3); else if (un == 8) V(8, 3); else V(4, 3); }
+        else { if (un == 1) V(1, 0); else if (un == 2) V(2, 0); else if (un == 8) V(8, 0); else V(4, 0); }
+#undef V
+    } else {
+        launch_variant<NANT, UNROLL, 1>(t, b, x, ruledists, hit, s, grid, rules_per_block);
+    }
     return frirl_host::check_launch("five_hip_rule_distance");
 }
 
@@ -108,17 +155,14 @@ extern "C" int five_hip_rule_distance(const frirl_hip_tables *t, const frirl_hip
     if ((rc = check_device())) return rc;
     hipStream_t s = as_stream(stream);
 
-    // Enough workgroups to fill 256 CUs x 8 (>= 4096) without making chunks shorter than one
-    // fully unrolled sweep (2048 rules).
-    const int min_chunk = 2048;
-    int chunks = (4096 + b->E - 1) / b->E;
-    const int max_chunks = (b->maxR + min_chunk - 1) / min_chunk;
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks < 1) chunks = 1;
-    if (chunks > 65535) chunks = 65535;
-    int rules_per_block = (b->maxR + chunks - 1) / chunks;
+    // Rule chunk per workgroup (A/B-measured): 1024 rules for rule bases up to 16 K rules, 8192 above; always
+    // a multiple of one 512-rule sweep.  grid = (environment, chunk) => >= 8 workgroups per environment at
+    // the BASELINE shapes, tens of thousands of short workgroups in total.
+    const int forced = frirl::rd_tune().chunk;
+    int rules_per_block = forced > 0 ? forced : (b->maxR <= 16384 + 512 ? 1024 : 8192);
     rules_per_block = ((rules_per_block + 2 * FRIRL_BLOCK - 1) / (2 * FRIRL_BLOCK)) * (2 * FRIRL_BLOCK);
-    chunks = (b->maxR + rules_per_block - 1) / rules_per_block;
+    int chunks = (b->maxR + rules_per_block - 1) / rules_per_block;
+    if (chunks > 65535) { rules_per_block = ((b->maxR / 65535 + 2 * FRIRL_BLOCK) / (2 * FRIRL_BLOCK)) * (2 * FRIRL_BLOCK); chunks = (b->maxR + rules_per_block - 1) / rules_per_block; }
     dim3 grid((unsigned)b->E, (unsigned)chunks);
 
     if (hipMemsetAsync(hit, 0xFF, sizeof(uint32_t) * (size_t)b->E, s) != hipSuccess) return check_launch("five_hip_rule_distance(memset)");

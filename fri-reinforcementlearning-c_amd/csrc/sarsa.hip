@@ -28,7 +28,8 @@ struct StepShared {
 template <int NANT, int BLOCK>
 __device__ int update_sarsa_block(const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ base,
                                   int maxR, int32_t *nrules_e, const frirl_hip_agent &ag, StepShared &sh, double reward,
-                                  bool qp_known, double qp, int32_t *fus_e, double *rant_e, BlockRed<BLOCK> &red)
+                                  bool qp_known, double qp, int32_t *fus_e, double *rant_e, BlockRed<BLOCK> &red,
+                                  const QResult *rn_known = nullptr)
 {
     const int R = *nrules_e;
     const int p = ag.p > 0 ? ag.p : NANT;
@@ -41,7 +42,7 @@ __device__ int update_sarsa_block(const double *__restrict__ u, const double *__
         const QResult rp = sweep_q<NANT, BLOCK>(base, maxR, R, q2, p, red);
         qp = (rp.hit != FRIRL_HIP_NO_HIT) ? qcol[rp.hit] : rp.vagc / rp.ws;
     }
-    const QResult rn = sweep_q<NANT, BLOCK>(base, maxR, R, q1, p, red);    // :357  Q(s,a)
+    const QResult rn = rn_known ? *rn_known : sweep_q<NANT, BLOCK>(base, maxR, R, q1, p, red);    // :357  Q(s,a)
     const double qnow = (rn.hit != FRIRL_HIP_NO_HIT) ? qcol[rn.hit] : rn.vagc / rn.ws;
     const double qdiff = ag.alpha * (reward + ag.gamma * qp - qnow);        // :358
     int fus = *fus_e;
@@ -236,7 +237,12 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
 #pragma unroll
     for (int k = 0; k < NS; k++) q[k] = sh.ve2[k];
     double *base = rb + (size_t)e * (NANT + 1) * maxR;
-    const int ap = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);    // :148
+    double q1[NANT];
+#pragma unroll
+    for (int k = 0; k < NANT; k++) q1[k] = sh.ve1[k];
+    QResult rn;
+    // one pass over the slab: greedy action for s' (:148) AND Q(s,a) of the pending update (frirl_update_sarsa.c:357)
+    const int ap = sweep_gba_q<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, rn);
     const double qp = gs.actconc[ap];          // == FIVE_vag_concl(cur_q_ant) of frirl_update_sarsa.c:356
     if (threadIdx.x == 0) {
         sh.cur_q_ant[NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + ap];                      // :151
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     }
     __syncthreads();
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
-    const int st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red);  // :159
+    const int st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn);  // :159
     if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
     if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.cur_q_ant[threadIdx.x];    // :166-168
     if (threadIdx.x == 0) {

@@ -21,6 +21,28 @@ __device__ __forceinline__ double pow_int(double b, int p)
     return r;
 }
 
+// Shepard weight 1/d^p from the SQUARED distance s = d^2 > 0 (reference: wi = 1.0 / fast_pow(fast_abs(d), p),
+// FIVEVagConcl.c:226, with d = sqrt(s)).  The reference's sqrt + p-1 multiplies + divide cost ~70 FP64
+// instructions per rule on CDNA4 (software sqrt and divide) and make the Q sweeps ALU-bound; here
+// y = rsqrt(s) (v_rsq_f64) is refined by two Newton steps (relative error ~1e-16, i.e. the same size as the
+// rounding of the reference's own sqrt/pow/divide chain) and raised to p by multiplication: ~20 instructions.
+// Exact-hit detection does not depend on it (d == 0 <=> s == 0).  Interpolated Q values are contractually
+// within 1e-6 relative of the reference (include/frirl_hip.h); materialised distances (five_hip_rule_distance)
+// keep the IEEE sqrt and stay bit-exact.
+__device__ __forceinline__ double inv_dist_pow(double s, int p)
+{
+    double y = __builtin_amdgcn_rsq(s);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const double t = s * y;
+        const double e = __fma_rn(-t, y, 1.0);
+        y = __fma_rn(0.5 * y, e, y);
+    }
+    double w = y;
+    for (int i = 1; i < p; i++) w = w * y;
+    return w;
+}
+
 template <int BLOCK>
 struct BlockRed {
     static constexpr int WAVES = BLOCK / FRIRL_WAVE;
@@ -96,18 +118,17 @@ __device__ QResult sweep_q(const double *__restrict__ base, int maxR, int R, con
         double a0, a1;
         sq_dist2<NANT>(base, maxR, r, q, a0, a1);
         const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
-        const double d0 = __dsqrt_rn(a0), d1 = __dsqrt_rn(a1);
-        if (d0 == 0.0) best = min(best, (unsigned)r);
+        if (a0 == 0.0) best = min(best, (unsigned)r);
         else {
-            const double wi = 1.0 / pow_int(d0, p);
+            const double wi = inv_dist_pow(a0, p);
             const double t = wi * c.x;
             sv = sv + t;
             sw = sw + wi;
         }
         if (r + 1 < R) {
-            if (d1 == 0.0) best = min(best, (unsigned)(r + 1));
+            if (a1 == 0.0) best = min(best, (unsigned)(r + 1));
             else {
-                const double wi = 1.0 / pow_int(d1, p);
+                const double wi = inv_dist_pow(a1, p);
                 const double t = wi * c.y;
                 sv = sv + t;
                 sw = sw + wi;
@@ -128,11 +149,12 @@ template <int NANT, int BLOCK>
 __device__ void sweep_weights(const double *__restrict__ base, int maxR, int R, const double (&q)[NANT], int p, double ws,
                               double *__restrict__ weights)
 {
+    const double iws = 1.0 / ws;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
         sq_dist2<NANT>(base, maxR, r, q, a0, a1);
-        const double w0 = (1.0 / pow_int(__dsqrt_rn(a0), p)) / ws;
-        const double w1 = (1.0 / pow_int(__dsqrt_rn(a1), p)) / ws;
+        const double w0 = inv_dist_pow(a0, p) * iws;
+        const double w1 = inv_dist_pow(a1, p) * iws;
         if (r + 1 < R) {
             double2 w; w.x = w0; w.y = w1;
             *reinterpret_cast<double2 *>(weights + r) = w;
@@ -148,11 +170,12 @@ __device__ void sweep_update(double *__restrict__ base, int maxR, int R, const d
                              double qdiff, double threshold, int r_skip)
 {
     double *__restrict__ qcol = base + (size_t)NANT * maxR;
+    const double iws = 1.0 / ws;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
         sq_dist2<NANT>(base, maxR, r, q, a0, a1);
-        const double w0 = (1.0 / pow_int(__dsqrt_rn(a0), p)) / ws;
-        const double w1 = (1.0 / pow_int(__dsqrt_rn(a1), p)) / ws;
+        const double w0 = inv_dist_pow(a0, p) * iws;
+        const double w1 = inv_dist_pow(a1, p) * iws;
         if (w0 > threshold && r != r_skip) { const double t = qdiff * w0; qcol[r] = qnow + t; }
         if (r + 1 < R && w1 > threshold && r + 1 != r_skip) { const double t = qdiff * w1; qcol[r + 1] = qnow + t; }
     }
@@ -198,10 +221,10 @@ __device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const
             if (a < A) {
                 const double e0 = av[a] - va.x, e1 = av[a] - va.y;
                 const double f0 = e0 * e0, f1 = e1 * e1;
-                const double d0 = __dsqrt_rn(f0 + s0), d1 = __dsqrt_rn(f1 + s1);
+                const double d0 = f0 + s0, d1 = f1 + s1;        // squared distances (K5 without the sqrt)
                 if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
                 else {
-                    const double wi = 1.0 / pow_int(d0, p);
+                    const double wi = inv_dist_pow(d0, p);
                     const double t = wi * c.x;
                     sv[a] = sv[a] + t;
                     sw[a] = sw[a] + wi;
@@ -209,7 +232,7 @@ __device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const
                 if (second) {
                     if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
                     else {
-                        const double wi = 1.0 / pow_int(d1, p);
+                        const double wi = inv_dist_pow(d1, p);
                         const double t = wi * c.y;
                         sv[a] = sv[a] + t;
                         sw[a] = sw[a] + wi;
@@ -239,6 +262,104 @@ __device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const
     if (threadIdx.x == 0) {
         int best = 0;
         for (int a = 1; a < A; a++) if (s.actconc[best] < s.actconc[a]) best = a;   // strict <: first maximum wins
+        s.best = best;
+    }
+    __syncthreads();
+    return s.best;
+}
+
+// Fused sweep of one environment step: the greedy sweep for the NEW state (sweep_gba) and the Q(s,a) sweep
+// for the pending update (sweep_q) read the same rule base, which nothing modifies in between
+// (frirl_episode.c:148 -> :159), so one pass over the slab serves both: 8*(nant+1) B per rule and step
+// instead of twice that.  Per-lane accumulation order and the reduction tree are those of the two separate
+// sweeps, so every result is bit-identical to running them one after the other.
+template <int NANT, int AMAX, int BLOCK>
+__device__ int sweep_gba_q(const double *__restrict__ base, int maxR, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
+                           const double (&q1)[NANT], int p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres)
+{
+    constexpr int NS = NANT - 1;
+    double sv[AMAX], sw[AMAX], av[AMAX];
+    unsigned sh[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; av[a] = (a < A) ? s.ave[a] : 0.0; }
+    unsigned qbest = FRIRL_HIP_NO_HIT;
+    double qv = 0.0, qw = 0.0;
+    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
+    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
+        double2 v[NANT];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) v[k] = *reinterpret_cast<const double2 *>(base + (size_t)k * maxR + r);
+        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        const bool second = (r + 1 < R);
+        // (1) Q(s,a): full distance to the pending antecedents
+        {
+            double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
+            double a0 = d0 * d0, a1 = d1 * d1;
+#pragma unroll
+            for (int k = 1; k < NANT; k++) {
+                d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
+                const double t0 = d0 * d0, t1 = d1 * d1;
+                a0 = a0 + t0; a1 = a1 + t1;
+            }
+            if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
+            else { const double wi = inv_dist_pow(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
+            if (second) {
+                if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
+                else { const double wi = inv_dist_pow(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
+            }
+        }
+        // (2) greedy sweep for the new state: state part once, then every action
+        double s0, s1;
+        {
+            double d0 = qs[0] - v[0].x, d1 = qs[0] - v[0].y;
+            s0 = d0 * d0; s1 = d1 * d1;
+#pragma unroll
+            for (int k = 1; k < NS; k++) {
+                d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
+                const double t0 = d0 * d0, t1 = d1 * d1;
+                s0 = s0 + t0; s1 = s1 + t1;
+            }
+        }
+        const double2 va = v[NS];
+#pragma unroll
+        for (int a = 0; a < AMAX; a++) {
+            if (a < A) {
+                const double e0 = av[a] - va.x, e1 = av[a] - va.y;
+                const double f0 = e0 * e0, f1 = e1 * e1;
+                const double d0 = f0 + s0, d1 = f1 + s1;        // squared distances
+                if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
+                else { const double wi = inv_dist_pow(d0, p); const double t = wi * c.x; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
+                if (second) {
+                    if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
+                    else { const double wi = inv_dist_pow(d1, p); const double t = wi * c.y; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
+                }
+            }
+        }
+    }
+    qres.hit = blk_min<BLOCK>(qbest, red);
+    qres.vagc = blk_sum<BLOCK>(qv, red);
+    qres.ws = blk_sum<BLOCK>(qw, red);
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+        if (a < A) {
+            const double tv = wave_sum_f64(sv[a]), tw = wave_sum_f64(sw[a]);
+            const unsigned th = wave_min_u32(sh[a]);
+            if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; s.h[wave][a] = th; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < A) {
+        const int a = threadIdx.x;
+        double tv = s.v[0][a], tw = s.w[0][a];
+        unsigned th = s.h[0][a];
+        for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; th = min(th, s.h[w][a]); }
+        s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int a = 1; a < A; a++) if (s.actconc[best] < s.actconc[a]) best = a;
         s.best = best;
     }
     __syncthreads();
