@@ -72,7 +72,14 @@ __global__ __launch_bounds__(BLOCK) void get_best_action_kernel(const double *__
 #pragma unroll
     for (int k = 0; k < NS; k++) q[k] = q_s[k];
     const double *base = rb + (size_t)e * (NANT + 1) * maxR;
-    const int b = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, R, q, p, A, gs);
+    int b;
+    if (AMAX > 8) {
+        __shared__ BlockRed<BLOCK> red;
+        double dummy[NANT] = {};
+        b = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(base, maxR, R, q, dummy, p, A, gs, red, nullptr);
+    } else {
+        b = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, R, q, p, A, gs);
+    }
     if ((int)threadIdx.x < A) actconc[(size_t)e * A + threadIdx.x] = gs.actconc[threadIdx.x];
     if (threadIdx.x == 0) best[e] = b;
 }
@@ -152,8 +159,7 @@ static void launch_gba(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
     } while (0)
     if (A <= 4) L(4);
     else if (A <= 8) L(8);
-    else if (A <= 16) L(16);
-    else L(32);
+    else L(32);            // > 8 actions: action-parallel waves (sweep_gba_wide)
 #undef L
 }
 

@@ -194,7 +194,14 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 #pragma unroll
     for (int k = 0; k < NS; k++) q[k] = q_s[k];
     const double *base = rb + (size_t)e * (NANT + 1) * maxR;
-    const int a0 = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);   // :78
+    int a0;
+    if (AMAX > 8) {
+        __shared__ BlockRed<BLOCK> red;
+        double dummy[NANT] = {};
+        a0 = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(base, maxR, nrules[e], q, dummy, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, nullptr);   // :78
+    } else {
+        a0 = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);   // :78
+    }
     if (threadIdx.x == 0) {
         ev.q_ant[(size_t)e * NANT + NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + a0];                 // :82
         ev.done[e] = 0;
@@ -242,7 +249,8 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     for (int k = 0; k < NANT; k++) q1[k] = sh.ve1[k];
     QResult rn;
     // one pass over the slab: greedy action for s' (:148) AND Q(s,a) of the pending update (frirl_update_sarsa.c:357)
-    const int ap = sweep_gba_q<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, rn);
+    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, &rn)
+                              : sweep_gba_q<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, rn);
     const double qp = gs.actconc[ap];          // == FIVE_vag_concl(cur_q_ant) of frirl_update_sarsa.c:356
     if (threadIdx.x == 0) {
         sh.cur_q_ant[NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + ap];                      // :151
@@ -341,8 +349,7 @@ static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases 
     } while (0)
     if (ag->A <= 4) L(4);
     else if (ag->A <= 8) L(8);
-    else if (ag->A <= 16) L(16);
-    else L(32);
+    else L(32);            // > 8 actions: action-parallel waves (sweep_gba_wide)
 #undef L
 }
 

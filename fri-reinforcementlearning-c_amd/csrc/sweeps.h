@@ -366,4 +366,102 @@ __device__ int sweep_gba_q(const double *__restrict__ base, int maxR, int R, con
     return s.best;
 }
 
+// Many-action form of the greedy sweep (A > 8, e.g. cartpole's 21 actions).  Keeping A accumulator pairs per
+// lane costs ~250 VGPRs at A = 21 (one wave per SIMD, every dependent FP64 chain exposed).  Here the ACTIONS
+// are split over the waves of the workgroup instead: wave w evaluates actions [w*ag, (w+1)*ag) with
+// ag = ceil(A / WAVES) <= AG for ALL rules (64 lanes x 2 rules per iteration); the waves read the same rule
+// columns almost simultaneously, so HBM still sees each rule once (L1/L2 absorb the repeats) while the
+// register footprint drops to AG accumulator pairs.  The optional Q(s,a) sums of the fused episode step are
+// spread over the waves by iteration.  Sums per action are one wave butterfly (deterministic).
+template <int NANT, int AG, int AMAX, int BLOCK, bool WITH_Q>
+__device__ int sweep_gba_wide(const double *__restrict__ base, int maxR, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
+                              const double (&q1)[NANT], int p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult *qres)
+{
+    constexpr int NS = NANT - 1;
+    constexpr int WAVES = BLOCK / FRIRL_WAVE;
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+    const int ag = (A + WAVES - 1) / WAVES;            // actions per wave (<= AG)
+    const int a_begin = wave * ag;
+    int na = A - a_begin;                              // actions of this wave
+    na = na < 0 ? 0 : (na > ag ? ag : na);
+    double sv[AG], sw[AG], av[AG];
+    unsigned sh[AG];
+#pragma unroll
+    for (int j = 0; j < AG; j++) { sv[j] = 0.0; sw[j] = 0.0; sh[j] = FRIRL_HIP_NO_HIT; av[j] = (j < na) ? s.ave[a_begin + j] : 0.0; }
+    unsigned qbest = FRIRL_HIP_NO_HIT;
+    double qv = 0.0, qw = 0.0;
+    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
+    int it = 0;
+    for (int r = 2 * lane; r < R; r += 2 * FRIRL_WAVE, it++) {
+        double2 v[NANT];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) v[k] = *reinterpret_cast<const double2 *>(base + (size_t)k * maxR + r);
+        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        const bool second = (r + 1 < R);
+        if (WITH_Q && (it % WAVES) == wave) {
+            double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
+            double a0 = d0 * d0, a1 = d1 * d1;
+#pragma unroll
+            for (int k = 1; k < NANT; k++) {
+                d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
+                const double t0 = d0 * d0, t1 = d1 * d1;
+                a0 = a0 + t0; a1 = a1 + t1;
+            }
+            if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
+            else { const double wi = inv_dist_pow(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
+            if (second) {
+                if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
+                else { const double wi = inv_dist_pow(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
+            }
+        }
+        double s0, s1;
+        {
+            double d0 = qs[0] - v[0].x, d1 = qs[0] - v[0].y;
+            s0 = d0 * d0; s1 = d1 * d1;
+#pragma unroll
+            for (int k = 1; k < NS; k++) {
+                d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
+                const double t0 = d0 * d0, t1 = d1 * d1;
+                s0 = s0 + t0; s1 = s1 + t1;
+            }
+        }
+        const double2 va = v[NS];
+#pragma unroll
+        for (int j = 0; j < AG; j++) {
+            if (j < na) {
+                const double e0 = av[j] - va.x, e1 = av[j] - va.y;
+                const double f0 = e0 * e0, f1 = e1 * e1;
+                const double d0 = f0 + s0, d1 = f1 + s1;
+                if (d0 == 0.0) sh[j] = min(sh[j], (unsigned)r);
+                else { const double wi = inv_dist_pow(d0, p); const double t = wi * c.x; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
+                if (second) {
+                    if (d1 == 0.0) sh[j] = min(sh[j], (unsigned)(r + 1));
+                    else { const double wi = inv_dist_pow(d1, p); const double t = wi * c.y; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < AG; j++) {
+        if (j < na) {
+            const double tv = wave_sum_f64(sv[j]), tw = wave_sum_f64(sw[j]);
+            const unsigned th = wave_min_u32(sh[j]);
+            if (lane == 0) s.actconc[a_begin + j] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
+        }
+    }
+    if (WITH_Q) {
+        qres->hit = blk_min<BLOCK>(qbest, red);
+        qres->vagc = blk_sum<BLOCK>(qv, red);
+        qres->ws = blk_sum<BLOCK>(qw, red);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int a = 1; a < A; a++) if (s.actconc[best] < s.actconc[a]) best = a;
+        s.best = best;
+    }
+    __syncthreads();
+    return s.best;
+}
+
 }  // namespace frirl
