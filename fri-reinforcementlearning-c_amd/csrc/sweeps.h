@@ -78,6 +78,17 @@ __device__ __forceinline__ double blk_sum(double v, BlockRed<BLOCK> &s)
     return t;
 }
 
+// Streaming 16-byte column load.  The sweeps read every rule once per pass and nothing is re-read before the
+// slab has left the caches, so the non-temporal hint applies (measured: episode step 0.459 -> 0.418 ms at cfg2).
+// (Issuing two column sets per iteration was tried and lost 15 %: registers, not memory parallelism, bind here.)
+__device__ __forceinline__ double2 load_col2(const double *__restrict__ p)
+{
+    double2 v;
+    v.x = __builtin_nontemporal_load(p);
+    v.y = __builtin_nontemporal_load(p + 1);
+    return v;
+}
+
 // Squared VE distance of two adjacent rules (r, r+1) to the observation q over dims [0, NDIM):
 // dimension-ordered, separate multiply and add (five_rule_distance.c:88-90,171-208).
 template <int NDIM>
@@ -85,7 +96,7 @@ __device__ __forceinline__ void sq_dist2(const double *__restrict__ base, int ma
 {
     double2 v[NDIM];
 #pragma unroll
-    for (int k = 0; k < NDIM; k++) v[k] = *reinterpret_cast<const double2 *>(base + (size_t)k * maxR + r);
+    for (int k = 0; k < NDIM; k++) v[k] = load_col2(base + (size_t)k * maxR + r);
     double d0 = q[0] - v[0].x, d1 = q[0] - v[0].y;
     a0 = d0 * d0;
     a1 = d1 * d1;
@@ -117,7 +128,7 @@ __device__ QResult sweep_q(const double *__restrict__ base, int maxR, int R, con
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
         sq_dist2<NANT>(base, maxR, r, q, a0, a1);
-        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        const double2 c = load_col2(qcol + r);
         if (a0 == 0.0) best = min(best, (unsigned)r);
         else {
             const double wi = inv_dist_pow(a0, p);
@@ -213,8 +224,8 @@ __device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double s0 = 0.0, s1 = 0.0;
         if (NS > 0) sq_dist2<(NS > 0 ? NS : 1)>(base, maxR, r, qs, s0, s1);
-        const double2 va = *reinterpret_cast<const double2 *>(acol + r);
-        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        const double2 va = load_col2(acol + r);
+        const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
 #pragma unroll
         for (int a = 0; a < AMAX; a++) {
@@ -288,8 +299,8 @@ __device__ int sweep_gba_q(const double *__restrict__ base, int maxR, int R, con
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double2 v[NANT];
 #pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = *reinterpret_cast<const double2 *>(base + (size_t)k * maxR + r);
-        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        for (int k = 0; k < NANT; k++) v[k] = load_col2(base + (size_t)k * maxR + r);
+        const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
         // (1) Q(s,a): full distance to the pending antecedents
         {
@@ -395,8 +406,8 @@ __device__ int sweep_gba_wide(const double *__restrict__ base, int maxR, int R, 
     for (int r = 2 * lane; r < R; r += 2 * FRIRL_WAVE, it++) {
         double2 v[NANT];
 #pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = *reinterpret_cast<const double2 *>(base + (size_t)k * maxR + r);
-        const double2 c = *reinterpret_cast<const double2 *>(qcol + r);
+        for (int k = 0; k < NANT; k++) v[k] = load_col2(base + (size_t)k * maxR + r);
+        const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
         if (WITH_Q && (it % WAVES) == wave) {
             double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
