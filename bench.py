@@ -119,10 +119,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("FRIRL_DIST_BACKEND", "nccl")     # "gloo" only to rehearse N > 1 on a one-GPU box
+    assert backend == "gloo" or local_rank < ndev, f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible"
+    torch.cuda.set_device(local_rank % ndev)
+    device = torch.device("cuda", local_rank % ndev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)      # RCCL over xGMI
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     if not (os.path.exists(frirl_amd.HIP_LIB_PATH) and os.path.exists(frirl_amd.DROPIN_LIB_PATH)):
