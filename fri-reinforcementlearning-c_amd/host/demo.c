@@ -21,12 +21,13 @@ int main(int argc, char **argv)
     struct frirl_desc fr = frirl_desc_default;
     const char *env = "mountaincar";
     char name[128];
-    int i, max_episodes = 0, fargc = 0;
+    int i, max_episodes = 0, fargc = 0, reduce = 0;
     char *fargv[16];
     fargv[fargc++] = argv[0];
     for (i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--env") && i + 1 < argc) env = argv[++i];
         else if (!strcmp(argv[i], "--max-episodes") && i + 1 < argc) max_episodes = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--reduce") && i + 1 < argc) reduce = atoi(argv[++i]);   /* construct, then reduce with strategy 1|2 */
         else if (fargc < 15) fargv[fargc++] = argv[i];
     }
     frirl_parse_cmdline(&fr, fargc, fargv);
@@ -34,6 +35,18 @@ int main(int argc, char **argv)
     if (max_episodes > 0) fr.max_episodes = max_episodes;
     if (frirl_init(&fr) != 0) { fprintf(stderr, "frirl_init failed\n"); return 1; }
     frirl_run(&fr, 1);
+    if (reduce == 1 || reduce == 2) {          /* the reference runs this phase from a saved .bin (mountaincar.c:240-242); same code path */
+        snprintf(name, sizeof name, "%s.frirlrb.txt", env);
+        frirl_save_rb_to_text_file(&fr, name);
+        fr.construct_rb = 0; fr.reduce_rb = 1; fr.reduction_strategy = (unsigned char)reduce;
+        frirl_sequential_run(&fr);
+        snprintf(name, sizeof name, "%s.reduced%d.frirlrb.txt", env, reduce);
+        frirl_save_rb_to_text_file(&fr, name);
+        printf("demo %s: reduced to %d rules (strategy %d)\n", env, fr.fiverb->numofrules, reduce);
+        frirl_deinit(&fr);
+        frirl_demo_release(&fr);
+        return 0;
+    }
     snprintf(name, sizeof name, "%s.frirlrb.bin", env);
     frirl_save_rb_to_bin_file(&fr, name);
     snprintf(name, sizeof name, "%s.frirlrb.txt", env);

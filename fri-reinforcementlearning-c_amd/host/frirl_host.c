@@ -288,20 +288,96 @@ void frirl_episode(struct frirl_desc *frirl)
 
 /* ---- run modes ------------------------------------------------------------------------------------ */
 
-/* reference src/frirl/frirl_sequential_run.c:24-165: incremental construction until the rule base,
- * step count and reward repeat and no consequent moved by >= qdiff_final_tolerance.  The reduction
- * phase (:170-350) is the next widening step and is not built yet. */
+/* Rule-base reduction, reference src/frirl/frirl_sequential_run.c:170-350 (strategies 1 and 2): take out the
+ * rule with the smallest (1) or largest (2) |Q| that is not yet marked important, replay one greedy episode
+ * without updates (reduction_state = 1); keep the removal if the episode still succeeds in the same number of
+ * steps with a reward within reduction_reward_tolerance, else reload the saved rule base and mark the rule
+ * important (its shadow consequent becomes NaN).  Every replay is GPU work (one greedy sweep per step);
+ * five_remove_rule compacts the device slab.  The undo buffer is the reference's temporary file. */
+static void frirl_reduce_rb(struct frirl_desc *frirl, double *prev_rconc, double prev_reward)
+{
+    static const char *tmpfile_name = "reduction_tmp.frirlrb.bin";
+    struct FIVERB *frb = frirl->fiverb;
+    const size_t bytes = sizeof(double) * frirl->five_maxnumofrules;
+    double *shadow = MALLOC(bytes), *removed = MALLOC(sizeof(double) * frb->rulelength);
+    int steps_incremental, iterations, redend = 0, j, k;
+    unsigned int mindex = 0;
+    if (!shadow || !removed) { fprintf(stderr, "frirl_sequential_run: out of memory\n"); exit(1); }
+    memcpy(shadow, frb->rconc, bytes);
+    frirl->original_learning = 1;
+    frirl->reduction_state = 1;
+    iterations = (frirl->reduction_strategy == 1 || frirl->reduction_strategy == 2) ? frb->numofrules + 1 : 10000;
+    frirl_episode(frirl);
+    steps_incremental = frirl->reward.ep_total_steps;
+    for (frirl->episode_num = 1; (int)frirl->episode_num <= iterations; frirl->episode_num++) {
+        frirl_episode(frirl);
+        printf("Reduction Episode: %d\tSteps: %d\tReward: %f\tEpsilon: %f\tRules: %d\n", frirl->episode_num, frirl->reward.ep_total_steps,
+               frirl->reward.ep_total_value, frirl->epsilon, frb->numofrules);
+        if (frirl->reduction_strategy != 1 && frirl->reduction_strategy != 2) continue;
+        if (frirl->episode_num > 1) {
+            const double diff = prev_reward - frirl->reward.ep_total_value;
+            if (frirl->reward.ep_total_value > frirl->reward_good_above && frirl->reward.ep_total_steps == steps_incremental &&
+                fabs(diff) <= frirl->reduction_reward_tolerance) {
+                if (frirl->verbose > 0) {
+                    printf("Reduction Episode: %d\tEliminated rule: no: %d. - ", frirl->episode_num, mindex + 1);
+                    for (j = 0; j < frb->rulelength; j++) printf(" %f", removed[j]);
+                    printf(" \tReward diff was: %f\n", diff);
+                }
+                prev_reward = frirl->reward.ep_total_value;
+            } else {
+                memcpy(shadow, prev_rconc, bytes);
+                shadow[mindex] = 0.0 / 0.0;                       /* important: never a candidate again */
+                if (frirl_load_rb_from_bin_file(frirl, tmpfile_name) < 0) { printf("Error while loading the binary rule-base file!\n"); exit(-1); }
+                frb = frirl->fiverb;
+                if (frirl->verbose > 0) {
+                    printf("Reduction Episode: %d\tRule stays: no: %d. - ", frirl->episode_num, mindex + 1);
+                    for (j = 0; j < frb->numofantecedents; j++) printf(" %f", frb->rseqant[j][mindex]);
+                    printf(" %f\n", frb->rconc[mindex]);
+                }
+            }
+        } else {
+            prev_reward = frirl->reward.ep_total_value;
+        }
+        {   /* next candidate; a NaN shadow value never wins against a number */
+            double mvalue = fabs(shadow[0]);
+            mindex = 0;
+            for (j = 1; j < frb->numofrules; j++) {
+                const int better = (frirl->reduction_strategy == 1) ? (mvalue > fabs(shadow[j])) : (mvalue < fabs(shadow[j]));
+                if (better || (mvalue != mvalue && shadow[j] == shadow[j])) { mvalue = fabs(shadow[j]); mindex = (unsigned int)j; }
+            }
+            if (mvalue != mvalue) {
+                if (frirl->verbose > 0) printf("Smallest rulebase found. Exiting.\n");
+                redend = 1;
+            } else {
+                frirl_save_rb_to_bin_file(frirl, tmpfile_name);
+                for (k = 0; k < frb->numofantecedents; k++) removed[k] = frb->rseqant[k][mindex];
+                removed[frb->rulelength - 1] = shadow[mindex];
+                memcpy(prev_rconc, shadow, bytes);
+                for (k = (int)mindex; k < frb->numofrules - 1; k++) shadow[k] = shadow[k + 1];
+                five_remove_rule(frb, mindex);
+            }
+        }
+        if (redend) break;
+    }
+    free(shadow);
+    free(removed);
+}
+
+/* reference src/frirl/frirl_sequential_run.c:24-355: incremental construction until the rule base, step count
+ * and reward repeat and no consequent moved by >= qdiff_final_tolerance (:55-165), then the optional reduction
+ * phase (:170-350). */
 void frirl_sequential_run(struct frirl_desc *frirl)
 {
     struct FIVERB *frb = frirl->fiverb;
     double *prev_rconc = MALLOC(sizeof(double) * frirl->five_maxnumofrules);
+    double prev_reward = frirl->reward.ep_total_value;
     int epchunk = 1, i;
     const int maxep = (frirl->runmode == FRIRL_MPI || frirl->runmode == FRIRL_OMP) ? FRIRL_AGENT_EPCHUNK : frirl->max_episodes;
     frirl->epended = 0;
+    memcpy(prev_rconc, frb->rconc, sizeof(double) * frirl->five_maxnumofrules);
     if (frirl->construct_rb == 1) {
         for (;;) {
             int prev_numru, prev_steps, epend = 0;
-            double prev_reward;
             if (!(epchunk < maxep)) {
                 if (!(frirl->episode_num < (unsigned int)frirl->max_episodes)) frirl->is_running = 0;
                 break;
@@ -341,8 +417,7 @@ void frirl_sequential_run(struct frirl_desc *frirl)
             epchunk++;
         }
     }
-    if (frirl->reduce_rb == 1)
-        printf("frirl_sequential_run: rule-base reduction is not part of this MI355X hot-path build (reference frirl_sequential_run.c:170-350); skipped.\n");
+    if (frirl->reduce_rb == 1) frirl_reduce_rb(frirl, prev_rconc, prev_reward);
     free(prev_rconc);
 }
 

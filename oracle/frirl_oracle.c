@@ -1013,3 +1013,87 @@ void orc_frirl_set_trace(orc_frirl *fr, void (*cb)(orc_frirl *, int, double, con
 {
     fr->trace = cb;
 }
+
+/* ------------------------------------------------------------------------- */
+/* rule-base reduction                                          */
+/* ------------------------------------------------------------------------- */
+/* src/frirl/frirl_sequential_run.c:170-350, strategies 1 (drop the smallest |Q| first) and 2 (largest |Q|
+ * first): remove a candidate rule, replay one greedy episode without updates (reduction_state = 1,
+ * frirl_episode.c:155); keep the removal if the episode still succeeds with the same step count and a reward
+ * within reduction_reward_tolerance (0.0 in every demo), otherwise restore the rule base and mark the rule as
+ * important (its shadow consequent becomes NaN).  The reference restores through a temporary .bin file whose
+ * loader re-adds every rule (frirl_utils.c:253-276); the in-memory snapshot below re-adds them the same way. */
+static void orc_episode_noupdate(orc_frirl *fr)
+{
+    const int ns = fr->nstates, n = ns + 1;
+    double states[ORC_MAX_NANT], cur_states[ORC_MAX_NANT], q_ant[ORC_MAX_NANT], cur_q_ant[ORC_MAX_NANT];
+    for (int i = 0; i < ns; i++) q_ant[i] = states[i] = fr->statedims[i].values_def;
+    fr->ep_total_value = 0; fr->ep_total_steps = 0;
+    unsigned ai = orc_e_greedy(fr, states);
+    q_ant[ns] = fr->actiondim.values[ai];
+    for (int step = 1; step <= fr->max_steps; step++) {
+        orc_env_do_action(fr, q_ant[ns], states, cur_states);
+        orc_env_get_reward(fr, cur_states, &fr->reward_value, &fr->success);
+        fr->ep_total_value += fr->reward_value;
+        orc_env_quantize(fr, cur_states, cur_q_ant);
+        unsigned pa = orc_e_greedy(fr, cur_q_ant);
+        cur_q_ant[ns] = fr->actiondim.values[pa];
+        for (int i = 0; i < ns; i++) states[i] = cur_states[i];
+        for (int i = 0; i < n; i++) q_ant[i] = cur_q_ant[i];
+        fr->ep_total_steps++;
+        if (fr->success == 1) break;
+    }
+}
+
+int orc_reduce_run(orc_frirl *fr, int strategy, double reward_tolerance)
+{
+    orc_five *f = fr->frb;
+    const int n = f->nant, maxR = fr->maxR;
+    double *tmp_rconc = (double *)malloc(sizeof(double) * maxR), *prev_rconc = (double *)malloc(sizeof(double) * maxR);
+    double *snap_rant = (double *)malloc(sizeof(double) * (size_t)maxR * n), *snap_rconc = (double *)malloc(sizeof(double) * maxR);
+    int snap_R = 0;
+    memcpy(tmp_rconc, f->rconc, sizeof(double) * maxR);
+    memcpy(prev_rconc, f->rconc, sizeof(double) * maxR);
+    const int iterations = f->R + 1;
+    double prev_reward = fr->ep_total_value;
+    unsigned mindex = 0;
+    int redend = 0;
+    orc_episode_noupdate(fr);                                   /* :196-197 */
+    const int steps_incremental = fr->ep_total_steps;
+    for (fr->episode_num = 1; (int)fr->episode_num <= iterations; fr->episode_num++) {
+        orc_episode_noupdate(fr);
+        if (fr->episode_num > 1) {                              /* :210-246 */
+            double diff = prev_reward - fr->ep_total_value;
+            if (fr->ep_total_value > fr->reward_good_above && fr->ep_total_steps == steps_incremental && fabs(diff) <= reward_tolerance) {
+                prev_reward = fr->ep_total_value;
+            } else {
+                memcpy(tmp_rconc, prev_rconc, sizeof(double) * maxR);
+                tmp_rconc[mindex] = 0.0 / 0.0;
+                while (f->R) f->R--;                            /* reload: numofrules = 0, then add every saved rule */
+                for (int r = 0; r < snap_R; r++) orc_add_rule(f, snap_rant + (size_t)r * n, snap_rconc[r]);
+                fr->fus_is_rule_inserted = 0;
+            }
+        } else {
+            prev_reward = fr->ep_total_value;
+        }
+        /* next candidate: smallest (strategy 1, :253-262) or largest (strategy 2, :291-300) |shadow Q|; NaN = important */
+        double mvalue = fabs(tmp_rconc[0]);
+        mindex = 0;
+        for (int j = 1; j < f->R; j++) {
+            int better = (strategy == 1) ? (mvalue > fabs(tmp_rconc[j])) : (mvalue < fabs(tmp_rconc[j]));
+            if (better || (mvalue != mvalue && tmp_rconc[j] == tmp_rconc[j])) { mvalue = fabs(tmp_rconc[j]); mindex = (unsigned)j; }
+        }
+        if (mvalue != mvalue) redend = 1;                       /* every remaining rule is important */
+        else {
+            snap_R = f->R;
+            memcpy(snap_rant, f->rant, sizeof(double) * (size_t)snap_R * n);
+            memcpy(snap_rconc, f->rconc, sizeof(double) * snap_R);
+            memcpy(prev_rconc, tmp_rconc, sizeof(double) * maxR);
+            for (int k = (int)mindex; k < f->R - 1; k++) tmp_rconc[k] = tmp_rconc[k + 1];
+            orc_remove_rule(f, mindex);
+        }
+        if (redend) break;
+    }
+    free(tmp_rconc); free(prev_rconc); free(snap_rant); free(snap_rconc);
+    return f->R;
+}

@@ -131,7 +131,8 @@ double orc_check_possible_states(double obs, const double *values, int values_le
 void orc_update_sarsa(orc_frirl *fr, const double *q_ant, double reward, const double *cur_q_ant); /* frirl_update_sarsa.c:348-385 */
 void orc_episode(orc_frirl *fr);                                                      /* frirl_episode.c:28-194 */
 int  orc_sequential_run(orc_frirl *fr, int verbose);                                  /* frirl_sequential_run.c:24-165 (construct loop) */
-int  orc_save_rb_text(orc_frirl *fr, const char *path);                               /* frirl_utils.c:100-144 */
+int  orc_save_rb_text(orc_frirl *fr, const char *path);
+int  orc_reduce_run(orc_frirl *fr, int strategy, double reward_tolerance);                /* frirl_sequential_run.c:170-350 */                               /* frirl_utils.c:100-144 */
 
 /* ---- environment dynamics (examples/<env>/<env>.c do_action/get_reward/quantize_observations) */
 void orc_env_do_action(const orc_frirl *fr, double action, const double *states, double *new_states);

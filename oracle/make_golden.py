@@ -10,6 +10,7 @@ reference's exported C API and each example's own main().  What is committed is 
   tests/golden/ref_<env>.frirlrb.txt  final rule base of the reference compiled HERE (construct mode)
   tests/golden/ref_<env>.trace.jsonl  first 400 steps, one record per episode and a running
                                       FNV-1a hash over every step of the whole run
+  tests/golden/ref_<env>.reduced<S>.frirlrb.txt  rule base after the reference's reduction phase (strategy S in 1, 2)
   tests/golden/vec_<env>.jsonl        function-level vectors (tables, index snap, rule distance,
                                       vag_concl, weights, best action, SARSA updates, env steps)
                                       on the rule base reached after a few episodes
@@ -58,6 +59,11 @@ def main():
         shutil.copyfile(os.path.join(tmp, f"{e}.trace.jsonl"), os.path.join(GOLD, f"ref_{e}.trace.jsonl"))
         with open(os.path.join(tmp, f"{e}.vstdout"), "w") as so:
             run(HARNESS, "vectors", e, os.path.join(GOLD, f"vec_{e}.jsonl"), str(VEC_EPISODES[e]), stdout=so)
+    for e in ENVS:
+        for strategy in (1, 2):
+            with open(os.path.join(tmp, f"{e}.rstdout"), "w") as so:
+                run(HARNESS, "reduce", e, tmp, str(strategy), stdout=so)
+            shutil.copyfile(os.path.join(tmp, f"{e}.reduced{strategy}.frirlrb.txt"), os.path.join(GOLD, f"ref_{e}.reduced{strategy}.frirlrb.txt"))
     for (nant, U, R, A, seed, nq) in SYNTH:
         run(HARNESS, "synth", str(nant), str(U), str(R), str(A), str(seed), str(nq),
             os.path.join(GOLD, f"synth_n{nant}_u{U}_r{R}.jsonl"))

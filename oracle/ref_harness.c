@@ -16,6 +16,8 @@
  *   vectors <env> <outfile> <nep>     run <nep> episodes, then function-level vectors on that rule base
  *   synth   <nant> <U> <R> <A> <seed> <nq> <outfile>   large synthetic bases (inputs from orc_synth_*)
  *   bench   <nant> <U> <R> <nq>       times five_rule_distance / FIVE_vag_concl (cpu_baseline "reference")
+ *   reduce  <env> <outdir> <strategy> construct run, then the reference's rule-base reduction
+ *                                     (frirl_sequential_run.c:170-350) on the result; <env>.reduced<strategy>.frirlrb.txt
  */
 #include <math.h>
 #include <stdio.h>
@@ -284,6 +286,18 @@ void harness_run(struct frirl_desc *fr, int verbose)
     fr->original_learning = 1;
     g_nstates = fr->statedims_len;
     o_do_action = fr->do_action_func; o_get_reward = fr->get_reward_func; o_quant = fr->quant_obs_func;
+    if (!strcmp(g_mode, "reduce")) {
+        char name[256];
+        frirl_run(fr, verbose);                                  /* construct */
+        fr->construct_rb = 0; fr->reduce_rb = 1; fr->reduction_strategy = g_nep;
+        frirl_sequential_run(fr);                                /* reduction phase only */
+        snprintf(name, sizeof name, "%s.reduced%d.frirlrb.txt", g_env, g_nep);
+        frirl_save_rb_to_text_file(fr, name);
+        fprintf(g_fp, "{\"k\":\"reduced\",\"env\":\"%s\",\"strategy\":%d,\"R\":%d,\"steps\":%d,\"reward\":", g_env, g_nep, fr->fiverb->numofrules,
+                fr->reward.ep_total_steps); jd(g_fp, fr->reward.ep_total_value); fprintf(g_fp, "}\n");
+        fr->reduce_rb = 0;
+        return;
+    }
     if (!strcmp(g_mode, "demo")) {
         fr->do_action_func = w_do_action; fr->get_reward_func = w_get_reward; fr->quant_obs_func = w_quant;
         fprintf(g_fp, "{\"k\":\"hdr\",\"env\":\"%s\",\"nstates\":%d,\"A\":%d,\"U\":%d}\n", g_env, fr->statedims_len,
@@ -394,6 +408,12 @@ int main(int argc, char **argv)
     if (!strcmp(g_mode, "demo")) {
         if (chdir(g_out) != 0) { perror("chdir"); return 1; }
         char p[256]; snprintf(p, sizeof p, "%s.trace.jsonl", g_env);
+        g_fp = fopen(p, "w");
+    } else if (!strcmp(g_mode, "reduce")) {
+        if (argc < 5) return 2;
+        g_nep = atoi(argv[4]);
+        if (chdir(g_out) != 0) { perror("chdir"); return 1; }
+        char p[256]; snprintf(p, sizeof p, "%s.reduce%d.jsonl", g_env, g_nep);
         g_fp = fopen(p, "w");
     } else if (!strcmp(g_mode, "vectors")) {
         if (argc < 5) return 2;

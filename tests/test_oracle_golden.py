@@ -278,3 +278,16 @@ def test_portable_trig_demo_converges_identically(env):
     fr = ob.Frirl(env, trig_mode=1)
     assert fr.run() == 1
     assert (fr.total_steps, fr.five.R) == EXPECT[env][0:1] + EXPECT[env][2:3]
+
+
+@pytest.mark.parametrize("env", ENVS)
+@pytest.mark.parametrize("strategy", [1, 2])
+def test_reduction_matches_reference(env, strategy, golden_dir, tmp_path):
+    """Rule-base reduction (reference frirl_sequential_run.c:170-350) after construction: byte-identical dump."""
+    fr = ob.Frirl(env)
+    assert fr.run() == 1
+    fr.reduce(strategy)
+    p = str(tmp_path / "red.txt")
+    fr.save_text(p)
+    with open(p) as a, open(os.path.join(golden_dir, f"ref_{env}.reduced{strategy}.frirlrb.txt")) as b:
+        assert a.read() == b.read()
