@@ -42,14 +42,21 @@ class AgentDesc(C.Structure):
     """struct frirl_hip_agent (include/frirl_hip.h)."""
     _fields_ = [("alpha", C.c_double), ("gamma", C.c_double), ("qdiff_pos_boundary", C.c_double), ("qdiff_neg_boundary", C.c_double),
                 ("weight_significant", C.c_double), ("skip_rules", C.c_int32), ("p", C.c_int32), ("A", C.c_int32), ("env_kind", C.c_int32),
-                ("max_steps", C.c_int32), ("reserved", C.c_int32), ("grid_len", C.c_int32 * MAX_NANT), ("grid_div", C.c_double * MAX_NANT),
-                ("values_def", C.c_double * MAX_NANT), ("grid_values", C.c_void_p), ("action_ve", C.c_void_p)]
+                ("max_steps", C.c_int32), ("no_random", C.c_int32), ("grid_len", C.c_int32 * MAX_NANT), ("grid_div", C.c_double * MAX_NANT),
+                ("values_def", C.c_double * MAX_NANT), ("grid_values", C.c_void_p), ("action_ve", C.c_void_p), ("epsilon", C.c_double),
+                ("reward_good_above", C.c_double), ("qdiff_final_tolerance", C.c_double), ("seed", C.c_uint64), ("env_id_base", C.c_uint64)]
 
 
 class EnvsDesc(C.Structure):
     """struct frirl_hip_envs (include/frirl_hip.h)."""
     _fields_ = [("states", C.c_void_p), ("q_ant", C.c_void_p), ("fus", C.c_void_p), ("done", C.c_void_p), ("ep_steps", C.c_void_p),
-                ("ep_reward", C.c_void_p), ("rant", C.c_void_p), ("status", C.c_void_p)]
+                ("ep_reward", C.c_void_p), ("rant", C.c_void_p), ("status", C.c_void_p), ("start_states", C.c_void_p), ("episode", C.c_void_p)]
+
+
+class ConvergenceDesc(C.Structure):
+    """struct frirl_hip_convergence (include/frirl_hip.h)."""
+    _fields_ = [("prev_nrules", C.c_void_p), ("prev_steps", C.c_void_p), ("prev_reward", C.c_void_p), ("prev_rconc", C.c_void_p),
+                ("converged", C.c_void_p), ("episodes", C.c_void_p)]
 
 
 _lib = None
@@ -74,6 +81,10 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "frirl_hip_episode_begin": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
     "frirl_hip_episode_step": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
+    "frirl_hip_episode_steps": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_int32, C.c_void_p]),
+    "frirl_hip_convergence_init": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(ConvergenceDesc), C.c_void_p]),
+    "frirl_hip_convergence_update": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
+                                               C.c_void_p]),
     "five_hip_bestact": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     # single rule base, host pointers (what the ANSI-C drop-in library calls)
     "five_hip_mirror_create": (C.c_void_p, [C.c_int32, C.c_int32, _DP, _DP, C.c_int32, C.c_int32]),
@@ -208,7 +219,8 @@ class Agent:
     """Host-side frirl_hip_agent: hyper-parameters + grids (device copies of the small tables are owned here)."""
 
     def __init__(self, device, nant, grids, grid_div, values_def, action_ve, alpha, gamma, qdiff_pos, qdiff_neg, weight_thr=0.05,
-                 skip_rules=1, p=0, env_kind=0, max_steps=1000):
+                 skip_rules=1, p=0, env_kind=0, max_steps=1000, epsilon=0.0, no_random=1, seed=0, reward_good_above=0.0,
+                 qdiff_final_tolerance=250.0, env_id_base=0):
         import numpy as np
         import torch
         assert len(grids) == nant and all(1 <= len(g) <= MAX_GRID for g in grids)
@@ -227,15 +239,19 @@ class Agent:
             d.grid_div[k] = grid_div[k] if k < len(grid_div) else 0.0
             d.values_def[k] = values_def[k] if k < len(values_def) else 0.0
         d.grid_values, d.action_ve = self.grid_values.data_ptr(), self.action_ve.data_ptr()
+        d.no_random, d.epsilon, d.seed, d.env_id_base = no_random, epsilon, seed, env_id_base
+        d.reward_good_above, d.qdiff_final_tolerance = reward_good_above, qdiff_final_tolerance
         self.desc, self.nant = d, nant
 
 
 class Envs:
     """Device-resident per-environment episode state (struct frirl_hip_envs)."""
 
-    def __init__(self, problem, device, keep_rant=True, rant_init=None):
+    def __init__(self, problem, device, keep_rant=True, rant_init=None, start_states=None):
         import torch
         E, nant, maxR = problem.E, problem.nant, problem.maxR
+        self.start_states = start_states
+        self.episode = torch.zeros((E,), dtype=torch.int32, device=device)
         self.states = torch.zeros((E, nant - 1), dtype=torch.float64, device=device)
         self.q_ant = torch.zeros((E, nant), dtype=torch.float64, device=device)
         self.fus = torch.zeros((E,), dtype=torch.int32, device=device)
@@ -247,7 +263,8 @@ class Envs:
         if keep_rant:
             self.rant = torch.zeros((E, nant, maxR), dtype=torch.float64, device=device) if rant_init is None else rant_init
         self.desc = EnvsDesc(self.states.data_ptr(), self.q_ant.data_ptr(), self.fus.data_ptr(), self.done.data_ptr(), self.ep_steps.data_ptr(),
-                             self.ep_reward.data_ptr(), self.rant.data_ptr() if self.rant is not None else None, self.status.data_ptr())
+                             self.ep_reward.data_ptr(), self.rant.data_ptr() if self.rant is not None else None, self.status.data_ptr(),
+                             self.start_states.data_ptr() if self.start_states is not None else None, self.episode.data_ptr())
 
 
 def update_sarsa(problem, agent, envs, q_ant, reward, cur_q_ant, active=None, stream=None):
@@ -308,6 +325,57 @@ def dropin():
     return _dropin
 
 
+def episode_steps(problem, agent, envs, nsteps, stream=None):
+    check(lib().frirl_hip_episode_steps(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), nsteps,
+                                        _stream(stream)), "frirl_hip_episode_steps")
+
+
+class Convergence:
+    """Device-resident construct-loop bookkeeping (struct frirl_hip_convergence)."""
+
+    def __init__(self, problem, device):
+        import torch
+        E, maxR = problem.E, problem.maxR
+        self.prev_nrules = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.prev_steps = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.prev_reward = torch.zeros((E,), dtype=torch.float64, device=device)
+        self.prev_rconc = torch.zeros((E, maxR), dtype=torch.float64, device=device)
+        self.converged = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.episodes = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.desc = ConvergenceDesc(self.prev_nrules.data_ptr(), self.prev_steps.data_ptr(), self.prev_reward.data_ptr(),
+                                    self.prev_rconc.data_ptr(), self.converged.data_ptr(), self.episodes.data_ptr())
+        check(lib().frirl_hip_convergence_init(C.byref(problem.bases), problem.nant, C.byref(self.desc), _stream()), "frirl_hip_convergence_init")
+
+    def update(self, problem, agent, envs, stream=None):
+        check(lib().frirl_hip_convergence_update(C.byref(problem.bases), problem.nant, C.byref(agent.desc), C.byref(envs.desc), C.byref(self.desc),
+                                                 _stream(stream)), "frirl_hip_convergence_update")
+
+
+def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None):
+    """Batched construct run: frirl_sequential_run's loop (reference frirl_sequential_run.c:55-165) for E agents
+    at once.  Episodes run until every environment's rule base is "considered complete" or max_episodes-1 episodes
+    have run (:51,59).  Converged environments are masked out of later episodes.  Returns the Convergence object."""
+    import torch
+    conv = Convergence(problem, problem.rb.device)
+    max_steps = agent.desc.max_steps
+    for ep in range(1, max_episodes):
+        episode_begin(problem, agent, envs)
+        envs.done.copy_(torch.maximum(envs.done, conv.converged))       # converged agents sit this episode out
+        steps = 0
+        while steps < max_steps:
+            n = min(check_every, max_steps - steps)
+            episode_steps(problem, agent, envs, n)
+            steps += n
+            if bool((envs.done != 0).all()):
+                break
+        conv.update(problem, agent, envs)
+        if on_episode is not None:
+            on_episode(ep, conv)
+        if bool((conv.converged != 0).all()):
+            break
+    return conv
+
+
 def demo_describe(env):
     """Tables, grids and hyper-parameters of a demo, built by the drop-in library's own host functions
     (frirl_init_ve etc.); no GPU needed."""
@@ -366,7 +434,37 @@ def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None):
     rb[:, nant, ncorner:R] = torch.rand((E, R - ncorner), generator=g, device=device, dtype=torch.float64) * 3000.0 - 1500.0
     nrules = torch.full((E,), R, dtype=torch.int32, device=device)
     prob = Problem(u_d, ve_d, rb, nrules)
-    agent = Agent(device, nant, d["grids"], d["grid_div"], d["values_def"], d["action_ve"], d["alpha"], d["gamma"], d["qdiff_pos"],
-                  d["qdiff_neg"], d["weight_thr"], d["skip_rules"], 0, d["kind"], max_steps or d["max_steps"])
+    agent = demo_agent(d, device, max_steps)
     envs = Envs(prob, device, rant_init=rant)
+    return prob, agent, envs
+
+
+def demo_agent(d, device, max_steps=None, **kw):
+    return Agent(device, d["nant"], d["grids"], d["grid_div"], d["values_def"], d["action_ve"], d["alpha"], d["gamma"], d["qdiff_pos"],
+                 d["qdiff_neg"], d["weight_thr"], d["skip_rules"], 0, d["kind"], max_steps or d["max_steps"],
+                 reward_good_above=d["reward_good_above"], qdiff_final_tolerance=d["qdiff_final_tolerance"], **kw)
+
+
+def demo_fresh_batch(env, E, maxR, device, start_states=None, **agent_kw):
+    """E agents of a demo starting from the reference's initial rule base: the 2^nant corner rules with Q = 0
+    (frirl_init_rb.c:99-126), grid min/max as antecedents.  Returns (Problem, Agent, Envs)."""
+    import numpy as np
+    import torch
+    d = demo_describe(env)
+    nant, U = d["nant"], d["U"]
+    ncorner = 2 ** nant
+    assert maxR % 2 == 0 and maxR >= ncorner
+    u_d, ve_d = torch.from_numpy(d["u"]).to(device), torch.from_numpy(d["ve"]).to(device)
+    rant0 = np.zeros((nant, ncorner))
+    for k in range(nant):
+        gk = d["grids"][k]
+        divider = ncorner >> (k + 1)
+        rant0[k] = [gk.min() if ((j // divider) % 2) == 0 else gk.max() for j in range(ncorner)]
+    prob = Problem(u_d, ve_d, torch.zeros((E, nant + 1, maxR), dtype=torch.float64, device=device),
+                   torch.zeros((E,), dtype=torch.int32, device=device))
+    agent = demo_agent(d, device, **agent_kw)
+    envs = Envs(prob, device, start_states=start_states)
+    for j in range(ncorner):        # FIVE_add_rule per corner, exactly as FIVEInit does for the initial rules
+        ra = torch.from_numpy(np.ascontiguousarray(rant0[:, j])).to(device).expand(E, nant).contiguous()
+        prob.add_rule(ra, torch.zeros((E,), dtype=torch.float64, device=device), rant_store=envs.rant)
     return prob, agent, envs

@@ -4,6 +4,8 @@
 // every decision of the reference's frirl_update_sarsa() is workgroup-uniform, so the whole TD step
 // -- Q(s',a'), Q(s,a), threshold test, grid snap, lookup of the snapped point, append or write-back --
 // runs inside one launch without inter-workgroup communication or atomics.
+#include <string.h>
+
 #include "envs.h"
 #include "sweeps.h"
 
@@ -21,6 +23,29 @@ struct StepShared {
     int success;
     int same;
 };
+
+// Counter-based per-environment random stream: SplitMix64 finaliser over (seed, env, episode, step, draw).
+// Stateless, so the trajectory of environment e does not depend on how environments are sharded over GPUs.
+__device__ __forceinline__ double rng_unit(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step, uint32_t draw)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * ((env << 32) | episode) + 0xD1B54A32D192ED03ULL * (((uint64_t)step << 8) | draw);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// frirl_e_greedy_selection (reference src/frirl/frirl_e_greedy_selection.c:21-37): greedy when no_random == 1 or
+// epsilon == 0 or the draw exceeds epsilon; otherwise a uniformly drawn action (the reference's index can equal A,
+// one past the last action; clamped here -- SURVEY Appendix C "fix in the batched path").
+__device__ __forceinline__ int e_greedy(const frirl_hip_agent &ag, int greedy, uint32_t env, uint32_t episode, uint32_t step)
+{
+    if (ag.no_random == 1 || ag.epsilon == 0.0) return greedy;
+    const uint64_t gid = ag.env_id_base + env;
+    if (rng_unit(ag.seed, gid, episode, step, 0) > ag.epsilon) return greedy;
+    int a = (int)round(rng_unit(ag.seed, gid, episode, step, 1) * ag.A);
+    return a >= ag.A ? ag.A - 1 : a;
+}
 
 // frirl_update_sarsa + update_rules (reference src/frirl/frirl_update_sarsa.c:348-385, :22-143).
 // `qp_known`: Q(s',a') already available (fused step: the greedy sweep produced it, identical
@@ -183,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
     __shared__ double q_s[NS];
     __shared__ GbaScratch<AMAX, BLOCK> gs;
     if (threadIdx.x < NS) {
-        const double v = ag.values_def[threadIdx.x];                          // q_states = states = values_def (:46-48)
+        const double v = ev.start_states ? ev.start_states[(size_t)e * NS + threadIdx.x] : ag.values_def[threadIdx.x];   // q_states = states = values_def (:46-48)
         ev.states[(size_t)e * NS + threadIdx.x] = v;
         ev.q_ant[(size_t)e * NANT + threadIdx.x] = v;
         q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, v);
@@ -203,6 +228,9 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
         a0 = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);   // :78
     }
     if (threadIdx.x == 0) {
+        const uint32_t epi = ev.episode ? (uint32_t)(ev.episode[e] + 1) : 0u;
+        if (ev.episode) ev.episode[e] = (int32_t)epi;
+        a0 = e_greedy(ag, a0, (uint32_t)e, epi, 0u);
         ev.q_ant[(size_t)e * NANT + NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + a0];                 // :82
         ev.done[e] = 0;
         ev.ep_steps[e] = 0;
@@ -251,12 +279,14 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     // one pass over the slab: greedy action for s' (:148) AND Q(s,a) of the pending update (frirl_update_sarsa.c:357)
     const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, &rn)
                               : sweep_gba_q<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, rn);
-    const double qp = gs.actconc[ap];          // == FIVE_vag_concl(cur_q_ant) of frirl_update_sarsa.c:356
     if (threadIdx.x == 0) {
-        sh.cur_q_ant[NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + ap];                      // :151
-        sh.ve2[NS] = gs.ave[ap];
+        const int chosen = e_greedy(ag, ap, (uint32_t)e, ev.episode ? (uint32_t)ev.episode[e] : 0u, (uint32_t)ev.ep_steps[e] + 1u);
+        gs.best = chosen;
+        sh.cur_q_ant[NS] = ag.grid_values[(size_t)NS * FRIRL_HIP_MAX_GRID + chosen];                  // :151
+        sh.ve2[NS] = gs.ave[chosen];
     }
     __syncthreads();
+    const double qp = gs.actconc[gs.best];     // Q(s',a') of the chosen action == FIVE_vag_concl(cur_q_ant), frirl_update_sarsa.c:356
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
     const int st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn);  // :159
     if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
@@ -267,6 +297,42 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
         ev.ep_reward[e] = ev.ep_reward[e] + sh.reward;                                                // :107
         if (sh.success == 1 || steps >= ag.max_steps) ev.done[e] = 1;                                 // :183, :86
         if (ev.status) ev.status[e] = st;
+    }
+}
+
+// frirl_sequential_run's construct-loop bookkeeping (reference src/frirl/frirl_sequential_run.c:68-72,83-148),
+// one workgroup per environment.
+__global__ __launch_bounds__(256) void convergence_kernel(const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
+                                                           int nant, const frirl_hip_agent ag, const frirl_hip_envs ev,
+                                                           const frirl_hip_convergence c, int init)
+{
+    const int e = blockIdx.x;
+    const double *qcol = rb + ((size_t)e * (nant + 1) + nant) * maxR;
+    double *prev = c.prev_rconc + (size_t)e * maxR;
+    const int R = nrules[e];
+    __shared__ int moved_s;
+    if (threadIdx.x == 0) moved_s = 0;
+    __syncthreads();
+    if (!init && !c.converged[e]) {
+        const bool same = c.prev_nrules[e] == R && c.prev_steps[e] == ev.ep_steps[e] && ev.ep_reward[e] > ag.reward_good_above &&
+                          c.prev_reward[e] == ev.ep_reward[e];                                            // :83-87
+        int moved = 0;
+        if (same)
+            for (int r = threadIdx.x; r < R; r += blockDim.x)
+                if (fabs(qcol[r] - prev[r]) >= ag.qdiff_final_tolerance) moved = 1;                    // :134-148
+        if (moved) atomicOr(&moved_s, 1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            c.episodes[e] = c.episodes[e] + 1;
+            if (same && !moved_s) c.converged[e] = 1;
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < maxR; r += blockDim.x) prev[r] = qcol[r];                               // :72
+    if (threadIdx.x == 0) {
+        c.prev_nrules[e] = R;                                                                             // :68-70
+        if (init) { c.prev_steps[e] = -1; c.prev_reward[e] = -1.0; c.converged[e] = 0; c.episodes[e] = 0; }   // frirl_init.c:149-150
+        else { c.prev_steps[e] = ev.ep_steps[e]; c.prev_reward[e] = ev.ep_reward[e]; }
     }
 }
 
@@ -384,4 +450,45 @@ extern "C" int frirl_hip_episode_step(const frirl_hip_tables *t, const frirl_hip
     if (t->nant == 3) launch_episode<3, false>(t, b, agent, envs, as_stream(stream));
     else launch_episode<5, false>(t, b, agent, envs, as_stream(stream));
     return check_launch("frirl_hip_episode_step");
+}
+
+extern "C" int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                                       const frirl_hip_envs *envs, int32_t nsteps, void *stream)
+{
+    int rc = check_episode(t, b, agent, envs, "frirl_hip_episode_steps");
+    if (rc) return rc;
+    for (int i = 0; i < nsteps; i++) {
+        if (t->nant == 3) launch_episode<3, false>(t, b, agent, envs, as_stream(stream));
+        else launch_episode<5, false>(t, b, agent, envs, as_stream(stream));
+    }
+    return check_launch("frirl_hip_episode_steps");
+}
+
+static int check_convergence(const frirl_hip_rulebases *b, const frirl_hip_convergence *c, const char *who)
+{
+    if (!b || !b->rb || !b->nrules || b->E < 1) { set_error("%s: bad rule bases", who); return FRIRL_HIP_EINVAL; }
+    if (!c || !c->prev_nrules || !c->prev_steps || !c->prev_reward || !c->prev_rconc || !c->converged || !c->episodes) { set_error("%s: NULL convergence state", who); return FRIRL_HIP_EINVAL; }
+    return check_device();
+}
+
+extern "C" int frirl_hip_convergence_init(const frirl_hip_rulebases *b, int nant, const frirl_hip_convergence *c, void *stream)
+{
+    int rc = check_convergence(b, c, "frirl_hip_convergence_init");
+    if (rc) return rc;
+    frirl_hip_agent ag;
+    frirl_hip_envs ev;
+    memset(&ag, 0, sizeof ag);
+    memset(&ev, 0, sizeof ev);
+    hipLaunchKernelGGL(frirl::convergence_kernel, dim3(b->E), dim3(256), 0, as_stream(stream), b->rb, b->nrules, b->maxR, nant, ag, ev, *c, 1);
+    return check_launch("frirl_hip_convergence_init");
+}
+
+extern "C" int frirl_hip_convergence_update(const frirl_hip_rulebases *b, int nant, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
+                                            const frirl_hip_convergence *c, void *stream)
+{
+    int rc = check_convergence(b, c, "frirl_hip_convergence_update");
+    if (rc) return rc;
+    if (!agent || !envs || !envs->ep_steps || !envs->ep_reward) { set_error("frirl_hip_convergence_update: NULL agent/envs"); return FRIRL_HIP_EINVAL; }
+    hipLaunchKernelGGL(frirl::convergence_kernel, dim3(b->E), dim3(256), 0, as_stream(stream), b->rb, b->nrules, b->maxR, nant, *agent, *envs, *c, 0);
+    return check_launch("frirl_hip_convergence_update");
 }

@@ -137,12 +137,18 @@ typedef struct frirl_hip_agent {
     int32_t A;                                 /* number of discrete actions                               */
     int32_t env_kind;                          /* FRIRL_HIP_ENV_*                                          */
     int32_t max_steps;                         /* frirl_desc.max_steps                                     */
-    int32_t reserved;
+    int32_t no_random;                         /* frirl_desc.no_random: 1 = always greedy (every demo)     */
     int32_t grid_len[FRIRL_HIP_MAX_NANT];      /* possible rule places per antecedent (states.., action)   */
     double grid_div[FRIRL_HIP_MAX_NANT];       /* statedims[i].values_div (generic quantiser)              */
     double values_def[FRIRL_HIP_MAX_NANT];     /* statedims[i].values_def: episode start state             */
     const double *grid_values;                 /* [dev] [nant][FRIRL_HIP_MAX_GRID]; row nant-1 = action values */
     const double *action_ve;                   /* [dev] [A] possible_actions->vevalues (frirl_init.c:156-158) */
+    double epsilon;                            /* frirl_desc.epsilon: exploration rate when no_random == 0 */
+    double reward_good_above;                  /* frirl_desc.reward_good_above   (convergence test)        */
+    double qdiff_final_tolerance;              /* frirl_desc.qdiff_final_tolerance (convergence test)      */
+    uint64_t seed;                             /* base seed of the per-environment counter-based RNG       */
+    uint64_t env_id_base;                      /* global id of environment 0 of this batch: RNG streams are keyed by the
+                                                  GLOBAL environment id, so trajectories do not depend on the sharding */
 } frirl_hip_agent;
 
 /* Per-environment episode state (reference: fields of frirl_desc + frirl_reward_desc that
@@ -156,7 +162,20 @@ typedef struct frirl_hip_envs {
     double *ep_reward;       /* [dev] [E] reward.ep_total_value                                           */
     double *rant;            /* [dev] [E][nant][maxR] raw antecedents of the rules (FIVERB.rant, SoA), or NULL */
     int32_t *status;         /* [dev] [E] FRIRL_HIP_UPD_* of the last update, or NULL                     */
+    const double *start_states; /* [dev] [E][nant-1] per-environment episode start state, or NULL = agent->values_def
+                                   (reference: gen_def_states randomises it per agent, frirl_agent.c:121-139) */
+    int32_t *episode;        /* [dev] [E] episodes started so far (RNG stream position), or NULL          */
 } frirl_hip_envs;
+
+/* Per-environment convergence state of the construct loop (reference frirl_sequential_run.c:55-165). */
+typedef struct frirl_hip_convergence {
+    int32_t *prev_nrules;    /* [dev] [E] rule count after the previous episode                           */
+    int32_t *prev_steps;     /* [dev] [E] steps of the previous episode                                   */
+    double *prev_reward;     /* [dev] [E] reward of the previous episode                                  */
+    double *prev_rconc;      /* [dev] [E][maxR] consequents after the previous episode                    */
+    int32_t *converged;      /* [dev] [E] 1 once "RB considered complete" (sticky)                        */
+    int32_t *episodes;       /* [dev] [E] episodes run until convergence (counts while not converged)     */
+} frirl_hip_convergence;
 
 /* ---- FIVE_add_rule (reference src/five/five_add_rule.c:47-95) ---------------------------------
  * Appends one rule per environment where active[e] != 0 (active == NULL: all): rb[e][k][R] =
@@ -195,6 +214,19 @@ int frirl_hip_episode_begin(const frirl_hip_tables *t, const frirl_hip_rulebases
                             const frirl_hip_envs *envs, void *stream);
 int frirl_hip_episode_step(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                            const frirl_hip_envs *envs, void *stream);
+/* nsteps consecutive frirl_hip_episode_step launches (finished environments are skipped inside the kernel) */
+int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                            const frirl_hip_envs *envs, int32_t nsteps, void *stream);
+
+/* ---- construct-loop bookkeeping of frirl_sequential_run (reference src/frirl/frirl_sequential_run.c:55-165),
+ *      per environment: after an episode, converged[e] = same #rules, #steps and reward as the previous episode,
+ *      reward > reward_good_above and no consequent moved by >= qdiff_final_tolerance (:83-148); then the
+ *      snapshot (prev_*) is refreshed (:68-72).  frirl_hip_convergence_init sets prev_steps = prev_reward = -1
+ *      (frirl_init.c:149-150) and snapshots the initial consequents.  Converged environments stay converged;
+ *      the caller masks them out of further episodes through envs->done. */
+int frirl_hip_convergence_init(const frirl_hip_rulebases *b, int nant, const frirl_hip_convergence *c, void *stream);
+int frirl_hip_convergence_update(const frirl_hip_rulebases *b, int nant, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
+                                 const frirl_hip_convergence *c, void *stream);
 
 /* ---- FIVEVagConcl_FRIRL_BestAct (reference src/five/FIVEVagConcl_FRIRL_BestAct.c:56-299) -------
  * Conclusion from PRECOMPUTED rule distances: first exact hit (d == 0) or Shepard interpolation.

@@ -1,0 +1,78 @@
+"""Batched construct runs on the GPU (frirl_sequential_run's loop for E agents: episode_begin / episode_steps /
+convergence_update) against the oracle's whole demo run with the portable trig.
+
+Every agent starts from the reference's initial 2^nant corner rule base and must end exactly where the oracle ends:
+same number of episodes, same rule count, same antecedents in the same order (bit-exact), consequents within the
+1e-6 contract (asserted at 1e-9)."""
+import numpy as np
+import pytest
+
+import frirl_amd
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env,episodes,steps,rules", [("mountaincar", 29, 15548, 110), ("cartpole", 58, 33002, 182), ("acrobot", 110, 21207, 367)])
+def test_batched_training_reaches_the_oracle_rule_base(env, episodes, steps, rules):
+    import torch
+    E = 6
+    dev = torch.device("cuda", 0)
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1 and fr.five.R == rules and fr.total_steps == steps       # the portable trig learns the same rule base size
+    prob, agent, envs = frirl_amd.demo_fresh_batch(env, E, 1024, dev)
+    total = torch.zeros((E,), dtype=torch.int64, device=dev)
+
+    def on_episode(ep, conv):
+        total.add_(envs.ep_steps.long() * (conv.episodes == ep).long())
+
+    conv = frirl_amd.train(prob, agent, envs, on_episode=on_episode)
+    torch.cuda.synchronize()
+    assert (conv.converged == 1).all()
+    assert (conv.episodes == episodes).all(), conv.episodes.tolist()
+    assert (total == steps).all(), total.tolist()
+    assert (prob.nrules == rules).all()
+    f = fr.five
+    rant = envs.rant[:, :, :rules].cpu().numpy()
+    assert (rant == f.rant[:rules].T[None]).all(), "antecedents / rule order"
+    q = prob.rb[:, prob.nant, :rules].cpu().numpy()
+    rel = np.abs(q - f.rconc[None, :rules]) / np.maximum(np.abs(f.rconc[None, :rules]), 1e-9)
+    assert rel.max() <= 1e-9, rel.max()
+
+
+def test_epsilon_greedy_streams():
+    """Exploration (frirl_e_greedy_selection.c:28-33, batched with a counter-based per-environment stream):
+    epsilon = 0 or no_random = 1 reproduce the greedy run; a seed reproduces itself; trajectories are keyed by the
+    GLOBAL environment id (independent of how the batch is sharded); the exploration rate is about epsilon."""
+    import torch
+    dev = torch.device("cuda", 0)
+    K = 120
+
+    def run(E, **kw):
+        prob, agent, envs = frirl_amd.demo_fresh_batch("acrobot", E, 512, dev, **kw)
+        frirl_amd.episode_begin(prob, agent, envs)
+        acts = []
+        for _ in range(K):
+            frirl_amd.episode_steps(prob, agent, envs, 1)
+            acts.append(envs.q_ant[:, prob.nant - 1].clone())
+        torch.cuda.synchronize()
+        return torch.stack(acts, 1), envs.states.clone(), prob.nrules.clone()
+
+    g_act, g_states, g_rules = run(8)
+    a0, s0, r0 = run(8, epsilon=0.0, no_random=0, seed=7)
+    assert (a0 == g_act).all() and (s0 == g_states).all()
+    a1, s1, r1 = run(8, epsilon=0.3, no_random=1, seed=7)
+    assert (a1 == g_act).all()
+    x_act, x_states, x_rules = run(8, epsilon=0.3, no_random=0, seed=7)
+    y_act, y_states, _ = run(8, epsilon=0.3, no_random=0, seed=7)
+    assert (x_act == y_act).all() and (x_states == y_states).all(), "same seed, same trajectory"
+    z_act, _, _ = run(8, epsilon=0.3, no_random=0, seed=8)
+    assert not (z_act == x_act).all()
+    assert not (x_act[0] == x_act[1]).all(), "environments have different streams"
+    # sharding invariance: environments 4..7 of the 8-batch == a 4-batch whose env_id_base is 4
+    h_act, h_states, _ = run(4, epsilon=0.3, no_random=0, seed=7, env_id_base=4)
+    assert (h_act == x_act[4:]).all() and (h_states == x_states[4:]).all()
+    # exploration rate: a random pick differs from the greedy pick 2/3 of the time (3 actions, clamped round() is not
+    # uniform: P = 1/6, 1/3, 1/2), so the observed deviation rate from a greedy replay is below epsilon; just bound it
+    dev_rate = (x_act != g_act).double().mean().item()
+    assert 0.02 < dev_rate < 0.6
