@@ -402,21 +402,28 @@ extern "C" int frirl_hip_env_step(const frirl_hip_agent *agent, int32_t E, int32
     return check_launch("frirl_hip_env_step");
 }
 
+template <int N, int AMAX, int BLOCK, bool BEGIN>
+static void launch_episode_v(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                             hipStream_t s)
+{
+    if (BEGIN) hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, BLOCK>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,
+                                  b->maxR, *ag, *ev);
+    else hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, BLOCK>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,
+                            b->maxR, *ag, *ev);
+}
+
+// Workgroup shape: 256 threads per environment for large rule bases (bandwidth); ONE wave per environment while
+// the rule bases are small (<= 2048 rules: the demos' real learning regime, <= 367 rules) -- no cross-wave
+// reductions or barriers on the critical path and 4x more environments resident per CU.  More than 8 actions
+// always use 256 threads (the action-parallel sweep needs the waves).
 template <int N, bool BEGIN>
 static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
                            hipStream_t s)
 {
-#define L(AMAX)                                                                                                                        \
-    do {                                                                                                                               \
-        if (BEGIN) hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, \
-                                      b->nrules, b->maxR, *ag, *ev);                                                                   \
-        else hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb,       \
-                                b->nrules, b->maxR, *ag, *ev);                                                                         \
-    } while (0)
-    if (ag->A <= 4) L(4);
-    else if (ag->A <= 8) L(8);
-    else L(32);            // > 8 actions: action-parallel waves (sweep_gba_wide)
-#undef L
+    const bool small = b->maxR <= 2048;
+    if (ag->A <= 4) { if (small) launch_episode_v<N, 4, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 4, 256, BEGIN>(t, b, ag, ev, s); }
+    else if (ag->A <= 8) { if (small) launch_episode_v<N, 8, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 8, 256, BEGIN>(t, b, ag, ev, s); }
+    else launch_episode_v<N, 32, 256, BEGIN>(t, b, ag, ev, s);            // > 8 actions: action-parallel waves (sweep_gba_wide)
 }
 
 static int check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
