@@ -86,6 +86,13 @@ SIGNATURES = {
     "frirl_hip_convergence_update": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
                                                C.c_void_p]),
     "five_hip_bestact": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # library-owned batch with host descriptors (C-level many-agent runner)
+    "frirl_hip_batch_create": (C.c_void_p, [C.c_void_p]),
+    "frirl_hip_batch_destroy": (None, [C.c_void_p]),
+    "frirl_hip_batch_episode": (C.c_int, [C.c_void_p]),
+    "frirl_hip_batch_train": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "frirl_hip_batch_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "frirl_hip_batch_get_rulebase": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _DP, _DP]),
     # single rule base, host pointers (what the ANSI-C drop-in library calls)
     "five_hip_mirror_create": (C.c_void_p, [C.c_int32, C.c_int32, _DP, _DP, C.c_int32, C.c_int32]),
     "five_hip_mirror_destroy": (None, [C.c_void_p]),

@@ -1,0 +1,204 @@
+// batch.hip -- library-owned batch of E agents with host descriptors (frirl_hip_batch_*): what a plain-C host
+// needs to run many agents on the GPU without touching the HIP runtime itself.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "device_common.h"
+
+using namespace frirl_host;
+
+struct frirl_hip_batch {
+    int32_t nant, U, E, maxR;
+    hipStream_t s;
+    double *d_u, *d_ve, *d_rb, *d_rant, *d_grid, *d_ave, *d_states, *d_q_ant, *d_ep_reward, *d_start, *d_prev_reward, *d_prev_rconc, *d_tmp;
+    int32_t *d_nrules, *d_fus, *d_done, *d_ep_steps, *d_status, *d_episode, *d_prev_nrules, *d_prev_steps, *d_converged, *d_episodes;
+    frirl_hip_tables t;
+    frirl_hip_rulebases rb;
+    frirl_hip_agent agent;
+    frirl_hip_envs envs;
+    frirl_hip_convergence conv;
+    int64_t total_env_steps;
+    std::vector<int32_t> h_i;
+    std::vector<double> h_d;
+};
+
+#define BCHK(call, what)                                                                                      \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(e_)); return FRIRL_HIP_ELAUNCH; } \
+    } while (0)
+
+template <typename T>
+static bool dalloc(T **p, size_t n)
+{
+    return hipMalloc((void **)p, n * sizeof(T)) == hipSuccess && hipMemset(*p, 0, n * sizeof(T)) == hipSuccess;
+}
+
+namespace frirl {
+// done[e] |= converged[e]: converged agents sit later episodes out
+__global__ void mask_converged_kernel(int32_t *__restrict__ done, const int32_t *__restrict__ converged, int E)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E && converged[e]) done[e] = 1;
+}
+// number of agents whose episode is still running -> *out
+__global__ void count_running_kernel(const int32_t *__restrict__ done, int E, int32_t *__restrict__ out)
+{
+    int n = 0;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) n += done[e] ? 0 : 1;
+    __shared__ int s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    if (n) atomicAdd(&s, n);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = s;
+}
+}  // namespace frirl
+
+extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
+{
+    if (!b) return;
+    if (b->s) (void)hipStreamSynchronize(b->s);
+    void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
+                    b->d_prev_rconc, b->d_tmp, b->d_nrules, b->d_fus, b->d_done, b->d_ep_steps, b->d_status, b->d_episode, b->d_prev_nrules,
+                    b->d_prev_steps, b->d_converged, b->d_episodes};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (b->s) (void)hipStreamDestroy(b->s);
+    delete b;
+}
+
+extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d)
+{
+    if (!d || !d->u || !d->ve || !d->agent.grid_values || !d->agent.action_ve || !d->rant0 || !d->rconc0) { set_error("frirl_hip_batch_create: NULL pointer"); return nullptr; }
+    if (d->nant < 2 || d->nant > 9 || d->U < 2 || d->E < 1 || d->maxR < 2 || d->R0 < 1 || d->R0 > d->maxR || d->agent.A < 1 || d->agent.A > FRIRL_HIP_MAX_ACTIONS) { set_error("frirl_hip_batch_create: bad sizes"); return nullptr; }
+    if (check_device()) return nullptr;
+    frirl_hip_batch *b = new frirl_hip_batch();
+    b->nant = d->nant; b->U = d->U; b->E = d->E; b->maxR = d->maxR + (d->maxR & 1);
+    const size_t E = (size_t)b->E, n = (size_t)b->nant, M = (size_t)b->maxR, ns = n - 1;
+    bool ok = hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && dalloc(&b->d_u, n * d->U) && dalloc(&b->d_ve, n * d->U) && dalloc(&b->d_rb, E * (n + 1) * M) && dalloc(&b->d_rant, E * n * M);
+    ok = ok && dalloc(&b->d_grid, (size_t)FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID) && dalloc(&b->d_ave, (size_t)FRIRL_HIP_MAX_ACTIONS);
+    ok = ok && dalloc(&b->d_states, E * ns) && dalloc(&b->d_q_ant, E * n) && dalloc(&b->d_ep_reward, E) && dalloc(&b->d_prev_reward, E);
+    ok = ok && dalloc(&b->d_prev_rconc, E * M) && dalloc(&b->d_tmp, E * (n + 1)) && dalloc(&b->d_nrules, E) && dalloc(&b->d_fus, E) && dalloc(&b->d_done, E);
+    ok = ok && dalloc(&b->d_ep_steps, E) && dalloc(&b->d_status, E) && dalloc(&b->d_episode, E) && dalloc(&b->d_prev_nrules, E) && dalloc(&b->d_prev_steps, E);
+    ok = ok && dalloc(&b->d_converged, E) && dalloc(&b->d_episodes, E + 1);
+    if (ok && d->start_states) ok = dalloc(&b->d_start, E * ns) && hipMemcpy(b->d_start, d->start_states, sizeof(double) * E * ns, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(b->d_u, d->u, sizeof(double) * n * d->U, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(b->d_ve, d->ve, sizeof(double) * n * d->U, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(b->d_grid, d->agent.grid_values, sizeof(double) * n * FRIRL_HIP_MAX_GRID, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(b->d_ave, d->agent.action_ve, sizeof(double) * d->agent.A, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { set_error("frirl_hip_batch_create: HIP allocation/copy failed: %s", hipGetErrorString(hipGetLastError())); frirl_hip_batch_destroy(b); return nullptr; }
+    b->t.nant = b->nant; b->t.U = b->U; b->t.u = b->d_u; b->t.ve = b->d_ve;
+    b->rb.E = b->E; b->rb.maxR = b->maxR; b->rb.rb = b->d_rb; b->rb.nrules = b->d_nrules;
+    b->agent = d->agent;
+    b->agent.grid_values = b->d_grid;
+    b->agent.action_ve = b->d_ave;
+    memset(&b->envs, 0, sizeof b->envs);
+    b->envs.states = b->d_states; b->envs.q_ant = b->d_q_ant; b->envs.fus = b->d_fus; b->envs.done = b->d_done; b->envs.ep_steps = b->d_ep_steps;
+    b->envs.ep_reward = b->d_ep_reward; b->envs.rant = b->d_rant; b->envs.status = b->d_status; b->envs.start_states = b->d_start; b->envs.episode = b->d_episode;
+    b->conv.prev_nrules = b->d_prev_nrules; b->conv.prev_steps = b->d_prev_steps; b->conv.prev_reward = b->d_prev_reward; b->conv.prev_rconc = b->d_prev_rconc;
+    b->conv.converged = b->d_converged; b->conv.episodes = b->d_episodes;
+    b->total_env_steps = 0;
+    // initial rules through FIVE_add_rule, as FIVEInit does (every agent gets the same R0 rules)
+    std::vector<double> stage(E * (n + 1));
+    for (int r = 0; r < d->R0; r++) {
+        for (size_t e = 0; e < E; e++) {
+            for (size_t k = 0; k < n; k++) stage[e * n + k] = d->rant0[(size_t)r * n + k];
+            stage[E * n + e] = d->rconc0[r];
+        }
+        if (hipMemcpyAsync(b->d_tmp, stage.data(), sizeof(double) * E * (n + 1), hipMemcpyHostToDevice, b->s) != hipSuccess ||
+            five_hip_add_rule(&b->t, &b->rb, b->d_tmp, b->d_tmp + E * n, nullptr, b->d_rant, nullptr, b->s) != 0 ||
+            hipStreamSynchronize(b->s) != hipSuccess) {
+            frirl_hip_batch_destroy(b);
+            return nullptr;
+        }
+    }
+    if (frirl_hip_convergence_init(&b->rb, b->nant, &b->conv, b->s) != 0 || hipStreamSynchronize(b->s) != hipSuccess) { frirl_hip_batch_destroy(b); return nullptr; }
+    return b;
+}
+
+extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
+{
+    if (!b) { set_error("frirl_hip_batch_episode: NULL batch"); return FRIRL_HIP_EINVAL; }
+    int rc = frirl_hip_episode_begin(&b->t, &b->rb, &b->agent, &b->envs, b->s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(frirl::mask_converged_kernel, dim3((b->E + 255) / 256), dim3(256), 0, b->s, b->d_done, b->d_converged, b->E);
+    const int chunk = 64;
+    int32_t running = 1;
+    for (int done_steps = 0; done_steps < b->agent.max_steps && running > 0; done_steps += chunk) {
+        const int nst = (b->agent.max_steps - done_steps < chunk) ? b->agent.max_steps - done_steps : chunk;
+        if ((rc = frirl_hip_episode_steps(&b->t, &b->rb, &b->agent, &b->envs, nst, b->s))) return rc;
+        hipLaunchKernelGGL(frirl::count_running_kernel, dim3(1), dim3(256), 0, b->s, b->d_done, b->E, b->d_episodes + b->E);
+        BCHK(hipMemcpyAsync(&running, b->d_episodes + b->E, sizeof(int32_t), hipMemcpyDeviceToHost, b->s), "running download");
+        BCHK(hipStreamSynchronize(b->s), "episode sync");
+    }
+    // account the steps of the agents that took part in this episode (converged ones keep ep_steps = 0)
+    b->h_i.resize(b->E);
+    BCHK(hipMemcpyAsync(b->h_i.data(), b->d_ep_steps, sizeof(int32_t) * b->E, hipMemcpyDeviceToHost, b->s), "steps download");
+    BCHK(hipStreamSynchronize(b->s), "steps sync");
+    for (int e = 0; e < b->E; e++) b->total_env_steps += b->h_i[e];
+    if ((rc = frirl_hip_convergence_update(&b->rb, b->nant, &b->agent, &b->envs, &b->conv, b->s))) return rc;
+    BCHK(hipStreamSynchronize(b->s), "convergence sync");
+    return check_launch("frirl_hip_batch_episode");
+}
+
+extern "C" int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *episodes_run)
+{
+    if (!b) { set_error("frirl_hip_batch_train: NULL batch"); return FRIRL_HIP_EINVAL; }
+    int ep = 0;
+    for (ep = 1; ep < max_episodes; ep++) {             // at most max_episodes-1 episodes (frirl_sequential_run.c:51,59)
+        int rc = frirl_hip_batch_episode(b);
+        if (rc) return rc;
+        b->h_i.resize(b->E);
+        BCHK(hipMemcpy(b->h_i.data(), b->d_converged, sizeof(int32_t) * b->E, hipMemcpyDeviceToHost), "converged download");
+        bool all = true;
+        for (int e = 0; e < b->E && all; e++) all = b->h_i[e] != 0;
+        if (all) { ep++; break; }
+    }
+    if (episodes_run) *episodes_run = ep - 1;
+    return FRIRL_HIP_OK;
+}
+
+extern "C" int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out)
+{
+    if (!b || !out) { set_error("frirl_hip_batch_stats: NULL"); return FRIRL_HIP_EINVAL; }
+    const int E = b->E;
+    std::vector<double> rew(E);
+    std::vector<int32_t> steps(E), nr(E), cv(E), eps(E);
+    BCHK(hipMemcpy(rew.data(), b->d_prev_reward, sizeof(double) * E, hipMemcpyDeviceToHost), "stats download");   // last finished episode
+    BCHK(hipMemcpy(steps.data(), b->d_prev_steps, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "stats download");
+    BCHK(hipMemcpy(nr.data(), b->d_nrules, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "stats download");
+    BCHK(hipMemcpy(cv.data(), b->d_converged, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "stats download");
+    BCHK(hipMemcpy(eps.data(), b->d_episodes, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "stats download");
+    memset(out, 0, sizeof *out);
+    out->agents = E;
+    out->reward_min = rew[0]; out->reward_max = rew[0];
+    for (int e = 0; e < E; e++) {
+        out->reward_sum += rew[e]; out->steps_sum += steps[e]; out->rules_sum += nr[e];
+        if (rew[e] < out->reward_min) out->reward_min = rew[e];
+        if (rew[e] > out->reward_max) out->reward_max = rew[e];
+        out->converged += cv[e] != 0;
+        if (eps[e] > out->episodes_max) out->episodes_max = eps[e];
+    }
+    out->total_env_steps = b->total_env_steps;
+    return FRIRL_HIP_OK;
+}
+
+extern "C" int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32_t *R, double *rant, double *rconc)
+{
+    if (!b || !R || e < 0 || e >= b->E) { set_error("frirl_hip_batch_get_rulebase: bad arguments"); return FRIRL_HIP_EINVAL; }
+    int32_t r = 0;
+    BCHK(hipMemcpy(&r, b->d_nrules + e, sizeof(int32_t), hipMemcpyDeviceToHost), "nrules download");
+    *R = r;
+    if (!rant || !rconc || r == 0) return FRIRL_HIP_OK;
+    const size_t n = b->nant, M = b->maxR;
+    std::vector<double> col(r);
+    for (size_t k = 0; k < n; k++) {
+        BCHK(hipMemcpy(col.data(), b->d_rant + ((size_t)e * n + k) * M, sizeof(double) * r, hipMemcpyDeviceToHost), "rant download");
+        for (int i = 0; i < r; i++) rant[(size_t)i * n + k] = col[i];
+    }
+    BCHK(hipMemcpy(rconc, b->d_rb + ((size_t)e * (n + 1) + n) * M, sizeof(double) * r, hipMemcpyDeviceToHost), "rconc download");
+    return FRIRL_HIP_OK;
+}

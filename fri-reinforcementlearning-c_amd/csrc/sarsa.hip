@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void convergence_kernel(const double *__restri
                                                            const frirl_hip_convergence c, int init)
 {
     const int e = blockIdx.x;
+    if (!init && c.converged[e]) return;      // sticky: a completed rule base keeps its last report (workgroup-uniform)
     const double *qcol = rb + ((size_t)e * (nant + 1) + nant) * maxR;
     double *prev = c.prev_rconc + (size_t)e * maxR;
     const int R = nrules[e];

@@ -21,16 +21,21 @@ int main(int argc, char **argv)
     struct frirl_desc fr = frirl_desc_default;
     const char *env = "mountaincar";
     char name[128];
-    int i, max_episodes = 0, fargc = 0, reduce = 0;
+    int i, max_episodes = 0, fargc = 0, reduce = 0, agents = 0;
     char *fargv[16];
     fargv[fargc++] = argv[0];
     for (i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--env") && i + 1 < argc) env = argv[++i];
         else if (!strcmp(argv[i], "--max-episodes") && i + 1 < argc) max_episodes = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--agents") && i + 1 < argc) agents = atoi(argv[++i]);      /* batched: N independent agents on the GPU */
         else if (!strcmp(argv[i], "--reduce") && i + 1 < argc) reduce = atoi(argv[++i]);   /* construct, then reduce with strategy 1|2 */
         else if (fargc < 15) fargv[fargc++] = argv[i];
     }
     frirl_parse_cmdline(&fr, fargc, fargv);
+    if (agents > 0) {
+        snprintf(name, sizeof name, "%s.batch.frirlrb.txt", env);
+        return frirl_demo_batch_run(env, agents, max_episodes > 0 ? max_episodes : fr.max_episodes, name, 1) == agents ? 0 : 3;
+    }
     if (frirl_demo_setup(&fr, env) != 0) return 2;
     if (max_episodes > 0) fr.max_episodes = max_episodes;
     if (frirl_init(&fr) != 0) { fprintf(stderr, "frirl_init failed\n"); return 1; }

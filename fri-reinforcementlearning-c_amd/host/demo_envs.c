@@ -18,6 +18,7 @@
 #include "frirl_app_helpers.h"
 #include "frirl_demo.h"
 #include "dropin_internal.h"
+#include "frirl_hip.h"
 
 #define PI 3.14159265358979323846264338327
 
@@ -237,4 +238,64 @@ int frirl_demo_describe(const char *env, int *nstates, int *U, int *A, double *u
     }
     frirl_demo_release(&fr);
     return 0;
+}
+
+/* E agents of a demo, batched on the device: the C-level counterpart of the reference's many-agent run modes
+ * (frirl_agent.c:294-467) without rule-base merging.  The environment's step() runs on the device with the portable
+ * trig (include/frirl_hip.h), so the learned rule bases equal the host demo's up to the trig's last-bit differences. */
+int frirl_demo_batch_run(const char *env, int agents, int max_episodes, const char *out_txt, int verbose)
+{
+    int ns, U, A, max_steps, nant, k, j, R0, episodes = 0, rc;
+    double *u, *ve, *grid, *action_ve, *rant0, *rconc0;
+    int grid_len[FRIRL_HIP_MAX_NANT];
+    double grid_div[FRIRL_HIP_MAX_NANT], values_def[FRIRL_HIP_MAX_NANT], hp[8];
+    frirl_hip_batch_desc d;
+    frirl_hip_batch *b;
+    frirl_hip_batch_stats_t st;
+    if (frirl_demo_describe(env, &ns, &U, &A, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, &max_steps) != 0) return -1;
+    nant = ns + 1;
+    u = malloc(sizeof(double) * nant * U); ve = malloc(sizeof(double) * nant * U);
+    grid = calloc((size_t)FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID, sizeof(double)); action_ve = calloc(FRIRL_HIP_MAX_ACTIONS, sizeof(double));
+    if (!u || !ve || !grid || !action_ve) return -1;
+    if (frirl_demo_describe(env, &ns, &U, &A, u, ve, grid, grid_len, grid_div, values_def, action_ve, hp, &max_steps) != 0) return -1;
+    R0 = 1 << nant;
+    rant0 = malloc(sizeof(double) * R0 * nant); rconc0 = calloc(R0, sizeof(double));
+    for (k = 0; k < nant; k++) {                               /* frirl_init_rb.c:99-126 */
+        double mn = grid[k * FRIRL_HIP_MAX_GRID], mx = mn;
+        const unsigned int divider = (unsigned int)R0 >> (k + 1);
+        for (j = 0; j < grid_len[k]; j++) { const double v = grid[k * FRIRL_HIP_MAX_GRID + j]; if (v > mx) mx = v; if (v < mn) mn = v; }
+        for (j = 0; j < R0; j++) rant0[j * nant + k] = (((j / divider) % 2) == 0) ? mn : mx;
+    }
+    memset(&d, 0, sizeof d);
+    d.nant = nant; d.U = U; d.E = agents; d.maxR = 1024; d.u = u; d.ve = ve; d.R0 = R0; d.rant0 = rant0; d.rconc0 = rconc0;
+    d.agent.alpha = hp[0]; d.agent.gamma = hp[1]; d.agent.qdiff_pos_boundary = hp[2]; d.agent.qdiff_neg_boundary = hp[3];
+    d.agent.weight_significant = hp[4]; d.agent.skip_rules = (int32_t)hp[5]; d.agent.reward_good_above = hp[6]; d.agent.qdiff_final_tolerance = hp[7];
+    d.agent.p = 0; d.agent.A = A; d.agent.max_steps = max_steps; d.agent.no_random = 1;
+    d.agent.env_kind = !strcmp(env, "mountaincar") ? FRIRL_HIP_ENV_MOUNTAINCAR : (!strcmp(env, "cartpole") ? FRIRL_HIP_ENV_CARTPOLE : FRIRL_HIP_ENV_ACROBOT);
+    for (k = 0; k < nant; k++) { d.agent.grid_len[k] = grid_len[k]; d.agent.grid_div[k] = grid_div[k]; d.agent.values_def[k] = values_def[k]; }
+    d.agent.grid_values = grid; d.agent.action_ve = action_ve;
+    b = frirl_hip_batch_create(&d);
+    if (!b) five_dropin_fatal("frirl_demo_batch_run(create)", FRIRL_HIP_ENODEV);
+    rc = frirl_hip_batch_train(b, max_episodes, &episodes);
+    if (rc) five_dropin_fatal("frirl_demo_batch_run(train)", rc);
+    rc = frirl_hip_batch_stats(b, &st);
+    if (rc) five_dropin_fatal("frirl_demo_batch_run(stats)", rc);
+    if (verbose)
+        printf("batch %s: agents %lld episodes %d converged %lld env-steps %lld mean-rules %.3f mean-reward %.6f (min %.6f max %.6f)\n", env,
+               (long long)st.agents, episodes, (long long)st.converged, (long long)st.total_env_steps, st.rules_sum / st.agents,
+               st.reward_sum / st.agents, st.reward_min, st.reward_max);
+    if (out_txt) {
+        int32_t R = 0;
+        double *rant = malloc(sizeof(double) * 1024 * nant), *rconc = malloc(sizeof(double) * 1024);
+        FILE *fp = fopen(out_txt, "w");
+        if (!rant || !rconc || !fp || frirl_hip_batch_get_rulebase(b, 0, &R, rant, rconc) != 0) { fprintf(stderr, "frirl_demo_batch_run: cannot dump rule base\n"); return -1; }
+        for (j = 0; j < R; j++) {
+            for (k = 0; k < nant; k++) fprintf(fp, "%.18f ", rant[j * nant + k]);
+            fprintf(fp, "%.18f \n", rconc[j]);
+        }
+        fclose(fp); free(rant); free(rconc);
+    }
+    frirl_hip_batch_destroy(b);
+    free(u); free(ve); free(grid); free(action_ve); free(rant0); free(rconc0);
+    return (int)st.converged;
 }

@@ -14,4 +14,10 @@ void frirl_demo_release(struct frirl_desc *fr);
 int frirl_demo_describe(const char *env, int *nstates, int *U, int *A, double *u, double *ve, double *grid, int *grid_len,
                         double *grid_div, double *values_def, double *action_ve, double *hparams, int *max_steps);
 
+/* Many independent agents of one demo on the GPU (frirl_hip_batch_*): every agent starts from the 2^nant corner
+ * rule base and learns until its rule base is complete (at most max_episodes-1 episodes).  Prints one summary line;
+ * when out_txt != NULL the rule base of agent 0 is written there in the reference's text format.
+ * Returns the number of converged agents, or -1 on error. */
+int frirl_demo_batch_run(const char *env, int agents, int max_episodes, const char *out_txt, int verbose);
+
 #endif

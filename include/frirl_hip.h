@@ -271,6 +271,42 @@ int five_hip_mirror_update_sarsa(five_hip_mirror *m, const frirl_hip_agent *agen
                                  const double *cur_q_ant, int32_t *fus, int32_t *status, double *new_rant, double *new_rconc,
                                  double *rconc);
 
+/* =================================================================================================
+ * Batch object, HOST descriptors: E agents of one problem owned by the library (device memory, stream,
+ * convergence state).  The C-level counterpart of the reference's many-agent run modes
+ * (frirl_omp_run / frirl_mpi_run, src/frirl/frirl_agent.c:294-467) without the rule-base merge: every
+ * agent owns its rule base and learns independently; only statistics leave the device.  The environment
+ * must be one of the built-in kinds (agent.env_kind), because its step() runs on the device.
+ * ================================================================================================= */
+typedef struct frirl_hip_batch frirl_hip_batch;
+
+typedef struct frirl_hip_batch_desc {
+    int32_t nant, U, E, maxR;
+    const double *u, *ve;             /* HOST [nant][U]                                                        */
+    frirl_hip_agent agent;            /* agent.grid_values: HOST [nant][FRIRL_HIP_MAX_GRID]; agent.action_ve: HOST [A] */
+    int32_t R0;                       /* initial rules of every agent (the 2^nant corner rules, frirl_init_rb.c:99-126) */
+    const double *rant0;              /* HOST [R0][nant] raw antecedents (AoS, like FIVERB.rant)               */
+    const double *rconc0;             /* HOST [R0]                                                             */
+    const double *start_states;       /* HOST [E][nant-1] per-agent episode start state, or NULL = agent.values_def */
+} frirl_hip_batch_desc;
+
+/* statistics of frirl_hip_batch_stats(): what the reference prints per episode (frirl_sequential_run.c:77-80), summed */
+typedef struct frirl_hip_batch_stats_t {
+    double reward_sum, steps_sum, rules_sum, reward_min, reward_max;
+    int64_t agents, converged, episodes_max, total_env_steps;
+} frirl_hip_batch_stats_t;
+
+frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d);
+void frirl_hip_batch_destroy(frirl_hip_batch *b);
+/* one episode for every not-yet-converged agent (frirl_episode), then the convergence bookkeeping */
+int frirl_hip_batch_episode(frirl_hip_batch *b);
+/* frirl_sequential_run's construct loop for all agents: at most max_episodes-1 episodes, stops when every agent's
+ * rule base is "considered complete"; *episodes_run receives the number of episodes executed */
+int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *episodes_run);
+int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out);
+/* rule base of agent e: *R rules, rant HOST [>= *R][nant] (AoS), rconc HOST [>= *R] (pass NULL to query *R only) */
+int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32_t *R, double *rant, double *rconc);
+
 #ifdef __cplusplus
 }
 #endif

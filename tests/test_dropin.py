@@ -138,3 +138,26 @@ def test_reduction_parity_through_dropin_api(env, strategy, built, tmp_path, gol
     assert (mine[:, :-1] == ref[:, :-1]).all()
     rel = np.abs(mine[:, -1] - ref[:, -1]) / np.maximum(np.abs(ref[:, -1]), 1e-9)
     assert rel.max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,rules", [("mountaincar", 110), ("acrobot", 367), ("cartpole", 182)])
+def test_c_level_batched_agents(env, rules, built, tmp_path):
+    """`frirl_demo --agents N`: N independent agents learn on the GPU through the C-level batch object
+    (frirl_hip_batch_*), no Python, no torch.  Every agent converges; agent 0's rule base equals the oracle's
+    (portable trig): antecedents bit-exact, consequents within 1e-6."""
+    from oracle import binding as ob
+    lib, demo = built
+    r = subprocess.run([demo, "--env", env, "--agents", "96"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "converged 96" in r.stdout, r.stdout
+    mine = load_rb(tmp_path / f"{env}.batch.frirlrb.txt")
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1
+    f = fr.five
+    assert mine.shape == (rules, f.nant + 1) and f.R == rules
+    assert (mine[:, :-1] == np.array(f.rant[:rules])).all()
+    rel = np.abs(mine[:, -1] - f.rconc[:rules]) / np.maximum(np.abs(f.rconc[:rules]), 1e-9)
+    assert rel.max() <= 1e-6
+    steps = {"mountaincar": 15548, "acrobot": 21207, "cartpole": 33002}[env]
+    assert f"env-steps {96 * steps}" in r.stdout, r.stdout
