@@ -288,7 +288,9 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     __syncthreads();
     const double qp = gs.actconc[gs.best];     // Q(s',a') of the chosen action == FIVE_vag_concl(cur_q_ant), frirl_update_sarsa.c:356
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
-    const int st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn);  // :159
+    int st = FRIRL_HIP_UPD_INACTIVE;
+    if (!ag.evaluate)                                                                                 // :155 (reduction_state == 0)
+        st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn);  // :159
     if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
     if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.cur_q_ant[threadIdx.x];    // :166-168
     if (threadIdx.x == 0) {

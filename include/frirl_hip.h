@@ -147,6 +147,9 @@ typedef struct frirl_hip_agent {
     double reward_good_above;                  /* frirl_desc.reward_good_above   (convergence test)        */
     double qdiff_final_tolerance;              /* frirl_desc.qdiff_final_tolerance (convergence test)      */
     uint64_t seed;                             /* base seed of the per-environment counter-based RNG       */
+    int32_t evaluate;                          /* 1 = policy roll-out only: no SARSA update (frirl_desc.reduction_state == 1,
+                                                  frirl_episode.c:155; frirl_test_run / the reduction replays)        */
+    int32_t reserved2;
     uint64_t env_id_base;                      /* global id of environment 0 of this batch: RNG streams are keyed by the
                                                   GLOBAL environment id, so trajectories do not depend on the sharding */
 } frirl_hip_agent;

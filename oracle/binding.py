@@ -97,6 +97,7 @@ def lib():
         "orc_sequential_run": (i, [vp, i]),
         "orc_save_rb_text": (i, [vp, C.c_char_p]),
         "orc_reduce_run": (i, [vp, i, d]),
+        "orc_episode_eval": (None, [vp]),
         "orc_env_do_action": (None, [vp, d, c_double_p, c_double_p]),
         "orc_env_get_reward": (None, [vp, c_double_p, c_double_p, C.POINTER(C.c_int)]),
         "orc_env_quantize": (None, [vp, c_double_p, c_double_p]),
@@ -353,6 +354,9 @@ class Frirl:
         if max_episodes is not None:
             lib().orc_frirl_set_max_episodes(self.h, max_episodes)
         return lib().orc_sequential_run(self.h, 0)
+
+    def episode_eval(self):
+        lib().orc_episode_eval(self.h)
 
     def reduce(self, strategy=1, reward_tolerance=0.0):
         return lib().orc_reduce_run(self.h, strategy, reward_tolerance)

@@ -1045,6 +1045,9 @@ static void orc_episode_noupdate(orc_frirl *fr)
     }
 }
 
+/* frirl_test_run's episode (src/frirl/frirl_test_run.c:20-86): one greedy roll-out, rule base untouched */
+void orc_episode_eval(orc_frirl *fr) { orc_episode_noupdate(fr); }
+
 int orc_reduce_run(orc_frirl *fr, int strategy, double reward_tolerance)
 {
     orc_five *f = fr->frb;

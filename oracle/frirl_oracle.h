@@ -132,7 +132,8 @@ void orc_update_sarsa(orc_frirl *fr, const double *q_ant, double reward, const d
 void orc_episode(orc_frirl *fr);                                                      /* frirl_episode.c:28-194 */
 int  orc_sequential_run(orc_frirl *fr, int verbose);                                  /* frirl_sequential_run.c:24-165 (construct loop) */
 int  orc_save_rb_text(orc_frirl *fr, const char *path);
-int  orc_reduce_run(orc_frirl *fr, int strategy, double reward_tolerance);                /* frirl_sequential_run.c:170-350 */                               /* frirl_utils.c:100-144 */
+int  orc_reduce_run(orc_frirl *fr, int strategy, double reward_tolerance);
+void orc_episode_eval(orc_frirl *fr);                                                 /* frirl_test_run.c:20-86 */                /* frirl_sequential_run.c:170-350 */                               /* frirl_utils.c:100-144 */
 
 /* ---- environment dynamics (examples/<env>/<env>.c do_action/get_reward/quantize_observations) */
 void orc_env_do_action(const orc_frirl *fr, double action, const double *states, double *new_states);

@@ -76,3 +76,29 @@ def test_epsilon_greedy_streams():
     # uniform: P = 1/6, 1/3, 1/2), so the observed deviation rate from a greedy replay is below epsilon; just bound it
     dev_rate = (x_act != g_act).double().mean().item()
     assert 0.02 < dev_rate < 0.6
+
+
+@pytest.mark.parametrize("env", ["mountaincar", "cartpole", "acrobot"])
+def test_evaluation_mode_rollout(env):
+    """policy roll-out without updates (frirl_test_run / reduction replays: reduction_state = 1,
+    frirl_episode.c:155).  Train on the device, then evaluate: the rule bases stay bit-identical and the greedy
+    episode equals the oracle's roll-out on its own trained rule base (steps and reward exactly)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    E = 4
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1
+    fr.episode_eval()
+    prob, agent, envs = frirl_amd.demo_fresh_batch(env, E, 1024, dev)
+    conv = frirl_amd.train(prob, agent, envs)
+    assert (conv.converged == 1).all()
+    before = prob.rb.clone()
+    nr = prob.nrules.clone()
+    d = frirl_amd.demo_describe(env)
+    ev_agent = frirl_amd.demo_agent(d, dev, evaluate=1)
+    frirl_amd.episode_begin(prob, ev_agent, envs)
+    frirl_amd.episode_steps(prob, ev_agent, envs, ev_agent.desc.max_steps)
+    torch.cuda.synchronize()
+    assert (prob.rb == before).all() and (prob.nrules == nr).all(), "evaluation must not touch the rule bases"
+    assert (envs.ep_steps == fr.ep_steps).all(), (envs.ep_steps.tolist(), fr.ep_steps)
+    assert (envs.ep_reward == fr.ep_reward).all()
