@@ -124,3 +124,50 @@ def test_episode_steps_full_size(batch):
     # every environment saw the same dynamics (same start state, mountaincar physics independent of the rule base
     # only through the chosen actions): rewards are -10 per step until success
     assert (envs.ep_reward == -10.0 * K).all()
+
+
+def test_cfg4_shape_sample_against_oracle():
+    """BASELINE cfg4 shape (acrobot tables, nant 5, 65536 rules per environment) on a reduced number of environments:
+    distances and hit indices bit-exact vs the oracle, Q values within tolerance, for every environment."""
+    import torch
+    En, Rn = 12, 65536
+    dev = torch.device("cuda", 0)
+    prob, agent, envs = frirl_amd.demo_batch("acrobot", En, Rn, Rn + 256, dev, seed=9)
+    nant = prob.nant
+    g = torch.Generator(device="cuda").manual_seed(2)
+    lo, hi = prob.u[:, 0], prob.u[:, prob.U - 2]
+    x = (lo + (hi - lo) * torch.rand((En, nant), generator=g, device="cuda", dtype=torch.float64)).contiguous()
+    x[0] = envs.rant[0, :, Rn - 1]                       # exact hit on the very last rule (or an earlier duplicate)
+    x[1] = envs.rant[1, :, 12345]
+    d, hit = prob.rule_distance(x)
+    conc, hitq = prob.vag_concl(x)
+    torch.cuda.synchronize()
+    assert (hit == hitq).all() and int(hit[0]) >= 0 and int(hit[1]) >= 0
+    u, ve = prob.u.cpu().numpy(), prob.ve.cpu().numpy()
+    xs = x.cpu().numpy()
+    for e in range(En):
+        rant = envs.rant[e, :, :Rn].T.contiguous().cpu().numpy()
+        rconc = prob.rb[e, nant, :Rn].cpu().numpy()
+        f = ob.Five(u.ravel(), ve.ravel(), nant, prob.U, Rn + 8, rant, rconc)
+        h = f.rule_distance(xs[e])
+        assert h == int(hit[e]), e
+        assert (d[e, :Rn].cpu().numpy().view(np.uint64) == np.array(f.ruledists[:Rn]).view(np.uint64)).all(), e
+        hq, c = f.vag_concl(xs[e])
+        assert hq == int(hitq[e])
+        assert float(conc[e]) == c if hq >= 0 else abs(float(conc[e]) - c) <= 1e-10 * max(abs(c), 1e-9)
+
+
+def test_run_to_run_determinism():
+    """No float atomics anywhere: two runs of the same fused steps from the same state give bit-identical rule bases."""
+    import torch
+    dev = torch.device("cuda", 0)
+    outs = []
+    for _ in range(2):
+        prob, agent, envs = frirl_amd.demo_batch("acrobot", 512, 4096, 4352, dev, seed=4)
+        frirl_amd.episode_begin(prob, agent, envs)
+        frirl_amd.episode_steps(prob, agent, envs, 12)
+        torch.cuda.synchronize()
+        outs.append((prob.rb.clone(), prob.nrules.clone(), envs.states.clone(), envs.status.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert (a == b).all()
+    assert (outs[0][3] == frirl_amd.UPD_SPREAD).any() or (outs[0][3] == frirl_amd.UPD_INSERTED).any()
