@@ -92,8 +92,8 @@ int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, in
  * For every environment e: ruledists[e][r] = sqrt(sum_k (ve[k][snap(x[e][k])] - rb[e][k][r])^2),
  * k ascending, for r < nrules[e]; hit[e] = lowest r < nrules[e] with distance exactly 0.0, else
  * FRIRL_HIP_NO_HIT.  snap() is the reference's fixed-step nearest-index rule
- * (src/inl/min.inl:71-92).  ruledists may be NULL (index-only form); entries r >= nrules[e] are
- * not written.
+ * (src/inl/min.inl:71-92).  ruledists may be NULL (index-only form); entries at or beyond nrules[e]
+ * rounded up to the next even index are not written (rules are processed in 16-byte pairs).
  *   x         [dev] [E][nant]   observations
  *   ruledists [dev] [E][maxR]   or NULL
  *   hit       [dev] [E]         uint32
