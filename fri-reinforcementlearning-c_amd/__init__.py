@@ -30,7 +30,7 @@ class Tables(C.Structure):
 
 class RuleBases(C.Structure):
     """struct frirl_hip_rulebases (include/frirl_hip.h)."""
-    _fields_ = [("E", C.c_int32), ("maxR", C.c_int32), ("rb", C.c_void_p), ("nrules", C.c_void_p)]
+    _fields_ = [("E", C.c_int32), ("maxR", C.c_int32), ("rb", C.c_void_p), ("nrules", C.c_void_p), ("uidx", C.c_void_p)]
 
 
 MAX_GRID = 64
@@ -157,7 +157,9 @@ def _stream(stream=None):
 class Problem:
     """Device-resident tables + E rule bases (torch tensors own the HBM; the C ABI gets raw pointers)."""
 
-    def __init__(self, u, ve, rb, nrules):
+    def __init__(self, u, ve, rb, nrules, uidx=None):
+        """uidx: optional int16 tensor [E, nant, maxR] holding the 16-bit universe indices of the antecedents
+        (frirl_hip_rulebases.uidx): the compressed mirror the scans stream instead of the f64 columns."""
         import torch
         assert u.is_cuda and ve.is_cuda and rb.is_cuda and nrules.is_cuda
         assert u.dtype == torch.float64 and ve.dtype == torch.float64 and rb.dtype == torch.float64 and nrules.dtype == torch.int32
@@ -165,8 +167,13 @@ class Problem:
         self.E, cols, self.maxR = rb.shape
         assert cols == self.nant + 1 and ve.shape == u.shape and nrules.shape == (self.E,)
         self.u, self.ve, self.rb, self.nrules = u.contiguous(), ve.contiguous(), rb.contiguous(), nrules.contiguous()
+        self.uidx = None
+        if uidx is not None:
+            assert uidx.is_cuda and uidx.dtype == torch.int16 and uidx.shape == (self.E, self.nant, self.maxR) and self.U <= 32767
+            self.uidx = uidx.contiguous()
         self.tables = Tables(self.nant, self.U, self.u.data_ptr(), self.ve.data_ptr())
-        self.bases = RuleBases(self.E, self.maxR, self.rb.data_ptr(), self.nrules.data_ptr())
+        self.bases = RuleBases(self.E, self.maxR, self.rb.data_ptr(), self.nrules.data_ptr(),
+                               self.uidx.data_ptr() if self.uidx is not None else None)
 
     def rule_distance(self, x, ruledists=None, hit=None, materialise=True, stream=None):
         """five_hip_rule_distance: returns (ruledists [E,maxR] or None, hit [E] int32 with -1 = none)."""
@@ -408,7 +415,7 @@ def demo_describe(env):
                 reward_good_above=hp[6], qdiff_final_tolerance=hp[7], max_steps=ms.value)
 
 
-def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None):
+def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None, compressed=True):
     """E environments of a demo on `device`, each with a private synthetic rule base of R rules: the 2^nant
     corner rules first (reference frirl_init_rb.c:99-126, Q = 0), then rules on the universe grid (uniform
     indices; action column on the A action values) with Q ~ U(-1500, 1500).
@@ -422,6 +429,7 @@ def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None):
     u_d, ve_d = torch.from_numpy(d["u"]).to(device), torch.from_numpy(d["ve"]).to(device)
     rb = torch.zeros((E, nant + 1, maxR), dtype=torch.float64, device=device)
     rant = torch.zeros((E, nant, maxR), dtype=torch.float64, device=device)
+    uidx = torch.zeros((E, nant, maxR), dtype=torch.int16, device=device) if compressed else None
     ncorner = 2 ** nant
     # action universe index of every action value (nearest universe point, as FIVE_add_rule snaps it)
     ua = d["u"][nant - 1]
@@ -437,10 +445,12 @@ def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None):
         idx[:, :ncorner] = corner[None]
         rb[:, k, :R] = ve_d[k][idx]
         rant[:, k, :R] = u_d[k][idx]
+        if compressed:
+            uidx[:, k, :R] = idx.to(torch.int16)
         del idx
     rb[:, nant, ncorner:R] = torch.rand((E, R - ncorner), generator=g, device=device, dtype=torch.float64) * 3000.0 - 1500.0
     nrules = torch.full((E,), R, dtype=torch.int32, device=device)
-    prob = Problem(u_d, ve_d, rb, nrules)
+    prob = Problem(u_d, ve_d, rb, nrules, uidx)
     agent = demo_agent(d, device, max_steps)
     envs = Envs(prob, device, rant_init=rant)
     return prob, agent, envs
@@ -468,7 +478,7 @@ def demo_fresh_batch(env, E, maxR, device, start_states=None, **agent_kw):
         divider = ncorner >> (k + 1)
         rant0[k] = [gk.min() if ((j // divider) % 2) == 0 else gk.max() for j in range(ncorner)]
     prob = Problem(u_d, ve_d, torch.zeros((E, nant + 1, maxR), dtype=torch.float64, device=device),
-                   torch.zeros((E,), dtype=torch.int32, device=device))
+                   torch.zeros((E,), dtype=torch.int32, device=device), torch.zeros((E, nant, maxR), dtype=torch.int16, device=device))
     agent = demo_agent(d, device, **agent_kw)
     envs = Envs(prob, device, start_states=start_states)
     for j in range(ncorner):        # FIVE_add_rule per corner, exactly as FIVEInit does for the initial rules

@@ -91,7 +91,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
     ok = ok && hipMemcpy(b->d_ave, d->agent.action_ve, sizeof(double) * d->agent.A, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { set_error("frirl_hip_batch_create: HIP allocation/copy failed: %s", hipGetErrorString(hipGetLastError())); frirl_hip_batch_destroy(b); return nullptr; }
     b->t.nant = b->nant; b->t.U = b->U; b->t.u = b->d_u; b->t.ve = b->d_ve;
-    b->rb.E = b->E; b->rb.maxR = b->maxR; b->rb.rb = b->d_rb; b->rb.nrules = b->d_nrules;
+    b->rb.E = b->E; b->rb.maxR = b->maxR; b->rb.rb = b->d_rb; b->rb.nrules = b->d_nrules; b->rb.uidx = nullptr;
     b->agent = d->agent;
     b->agent.grid_values = b->d_grid;
     b->agent.action_ve = b->d_ave;

@@ -90,6 +90,75 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_kernel(
     if (threadIdx.x == 0 && best != FRIRL_HIP_NO_HIT) atomicMin(&hit[e], best);
 }
 
+
+// Compressed-antecedent form: the rule base's 2-byte universe indices are streamed (4 B per lane and column:
+// two rules) and the VE values come from an LDS copy of the vague-environment tables.  Same arithmetic on the
+// same operands as above => bit-identical distances; HBM traffic 2*nant B read (+8 B written) per rule.
+template <int NANT, bool WRITE, int UNROLL>
+__global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_idx_kernel(
+    const double *__restrict__ u, const double *__restrict__ ve, int U, const uint16_t *__restrict__ uidx,
+    const int32_t *__restrict__ nrules, int maxR, const double *__restrict__ x, double *__restrict__ dists,
+    uint32_t *__restrict__ hit, int rules_per_block)
+{
+    extern __shared__ double tab_s[];            // [NANT][U] vague environments
+    const int e = blockIdx.x;
+    const int R = nrules[e];
+    const int r0 = blockIdx.y * rules_per_block;
+    if (r0 >= R) return;
+    int r_end = r0 + rules_per_block;
+    if (r_end > R) r_end = R;
+
+    __shared__ double q_s[NANT];
+    __shared__ unsigned red_s[FRIRL_WAVES_PER_BLOCK];
+    for (int i = threadIdx.x; i < NANT * U; i += FRIRL_BLOCK) tab_s[i] = ve[i];
+    if (threadIdx.x < NANT) q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, x[(size_t)e * NANT + threadIdx.x]);
+    __syncthreads();
+    double q[NANT];
+#pragma unroll
+    for (int k = 0; k < NANT; k++) q[k] = q_s[k];
+
+    const uint16_t *__restrict__ base = uidx + (size_t)e * NANT * maxR;
+    double *__restrict__ out = WRITE ? dists + (size_t)e * maxR : nullptr;
+    unsigned best = FRIRL_HIP_NO_HIT;
+    constexpr int STEP = FRIRL_BLOCK * 2;
+
+    for (int r = r0 + 2 * (int)threadIdx.x; r < r_end; r += STEP * UNROLL) {
+        uint32_t w[UNROLL][NANT];
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) {
+            const int rr = r + j * STEP;
+            if (rr < r_end) {
+#pragma unroll
+                for (int k = 0; k < NANT; k++) w[j][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(base + (size_t)k * maxR + rr));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) {
+            const int rr = r + j * STEP;
+            if (rr < r_end) {
+                double d0 = q[0] - tab_s[w[j][0] & 0xFFFFu], d1 = q[0] - tab_s[w[j][0] >> 16];
+                double a0 = d0 * d0, a1 = d1 * d1;
+#pragma unroll
+                for (int k = 1; k < NANT; k++) {
+                    d0 = q[k] - tab_s[k * U + (w[j][k] & 0xFFFFu)];
+                    d1 = q[k] - tab_s[k * U + (w[j][k] >> 16)];
+                    const double s0 = d0 * d0, s1 = d1 * d1;
+                    a0 = a0 + s0;
+                    a1 = a1 + s1;
+                }
+                double2 d;
+                d.x = __dsqrt_rn(a0);
+                d.y = __dsqrt_rn(a1);
+                if (WRITE) { __builtin_nontemporal_store(d.x, out + rr); __builtin_nontemporal_store(d.y, out + rr + 1); }
+                if (d.y == 0.0 && rr + 1 < R) best = min(best, (unsigned)(rr + 1));
+                if (d.x == 0.0) best = min(best, (unsigned)rr);
+            }
+        }
+    }
+    best = block_min_u32(best, red_s);
+    if (threadIdx.x == 0 && best != FRIRL_HIP_NO_HIT) atomicMin(&hit[e], best);
+}
+
 struct RdTune { int unroll, chunk, nt; };
 static RdTune rd_tune()
 {
@@ -126,6 +195,17 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
                        uint32_t *hit, hipStream_t s, dim3 grid, int rules_per_block)
 {
     constexpr int UNROLL = RdConfig<NANT>::UNROLL;
+    const size_t tab_bytes = sizeof(double) * NANT * (size_t)t->U;
+    if (b->uidx && t->U <= 65536 && tab_bytes <= 48 * 1024 && !getenv("FRIRL_HIP_NO_UIDX")) {
+        constexpr int UI = (NANT <= 8) ? 4 : 2;
+        if (ruledists)
+            hipLaunchKernelGGL((rule_distance_idx_kernel<NANT, true, UI>), grid, dim3(FRIRL_BLOCK), tab_bytes, s, t->u, t->ve, t->U, b->uidx,
+                               b->nrules, b->maxR, x, ruledists, hit, rules_per_block);
+        else
+            hipLaunchKernelGGL((rule_distance_idx_kernel<NANT, false, UI>), grid, dim3(FRIRL_BLOCK), tab_bytes, s, t->u, t->ve, t->U, b->uidx,
+                               b->nrules, b->maxR, x, ruledists, hit, rules_per_block);
+        return frirl_host::check_launch("five_hip_rule_distance(uidx)");
+    }
     const RdTune tn = rd_tune();
     if (NANT <= 5 && (tn.unroll || tn.nt >= 0)) {      // tuning hooks (experiments only)
         const int un = tn.unroll ? tn.unroll : UNROLL;
@@ -160,6 +240,7 @@ extern "C" int five_hip_rule_distance(const frirl_hip_tables *t, const frirl_hip
     // the BASELINE shapes, tens of thousands of short workgroups in total.
     const int forced = frirl::rd_tune().chunk;
     int rules_per_block = forced > 0 ? forced : (b->maxR <= 16384 + 512 ? 1024 : 8192);
+    if (b->uidx && forced <= 0) rules_per_block = 2048;      // compressed form: the LDS table fill is amortised over a longer chunk
     rules_per_block = ((rules_per_block + 2 * FRIRL_BLOCK - 1) / (2 * FRIRL_BLOCK)) * (2 * FRIRL_BLOCK);
     int chunks = (b->maxR + rules_per_block - 1) / rules_per_block;
     if (chunks > 65535) { rules_per_block = ((b->maxR / 65535 + 2 * FRIRL_BLOCK) / (2 * FRIRL_BLOCK)) * (2 * FRIRL_BLOCK); chunks = (b->maxR + rules_per_block - 1) / rules_per_block; }

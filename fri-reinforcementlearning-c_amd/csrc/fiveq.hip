@@ -7,23 +7,27 @@
 
 namespace frirl {
 
-template <int NANT, int BLOCK>
+template <int NANT, int BLOCK, bool IDX>
 __global__ __launch_bounds__(BLOCK) void vag_concl_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                           const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
+                                                           const double *__restrict__ rb, const uint16_t *__restrict__ uidx,
+                                                           const int32_t *__restrict__ nrules, int maxR,
                                                            int p, const double *__restrict__ x, double *__restrict__ conc,
                                                            uint32_t *__restrict__ hit)
 {
+    extern __shared__ double tab_s[];
     const int e = blockIdx.x;
     const int R = nrules[e];
     __shared__ double q_s[NANT];
     __shared__ BlockRed<BLOCK> red;
+    if (IDX) for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x < NANT) q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, x[(size_t)e * NANT + threadIdx.x]);
     __syncthreads();
     double q[NANT];
 #pragma unroll
     for (int k = 0; k < NANT; k++) q[k] = q_s[k];
     const double *base = rb + (size_t)e * (NANT + 1) * maxR;
-    const QResult res = sweep_q<NANT, BLOCK>(base, maxR, R, q, p, red);
+    const auto cols = ColsSel<IDX>::make(base, uidx + (IDX ? (size_t)e * NANT * maxR : 0), tab_s, maxR, U);
+    const QResult res = sweep_q<NANT, BLOCK>(cols, base + (size_t)NANT * maxR, R, q, p, red);
     if (threadIdx.x == 0) {
         hit[e] = res.hit;
         // exact hit -> its consequent (FIVEVagConcl.c:94-99); else vagc / ws (:302,347)
@@ -31,31 +35,36 @@ __global__ __launch_bounds__(BLOCK) void vag_concl_kernel(const double *__restri
     }
 }
 
-template <int NANT, int BLOCK>
+template <int NANT, int BLOCK, bool IDX>
 __global__ __launch_bounds__(BLOCK) void vag_concl_weight_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                                  const double *__restrict__ rb, const int32_t *__restrict__ nrules,
+                                                                  const double *__restrict__ rb, const uint16_t *__restrict__ uidx,
+                                                                  const int32_t *__restrict__ nrules,
                                                                   int maxR, int p, const double *__restrict__ x,
                                                                   double *__restrict__ weights, uint32_t *__restrict__ hit)
 {
+    extern __shared__ double tab_s[];
     const int e = blockIdx.x;
     const int R = nrules[e];
     __shared__ double q_s[NANT];
     __shared__ BlockRed<BLOCK> red;
+    if (IDX) for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x < NANT) q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, x[(size_t)e * NANT + threadIdx.x]);
     __syncthreads();
     double q[NANT];
 #pragma unroll
     for (int k = 0; k < NANT; k++) q[k] = q_s[k];
     const double *base = rb + (size_t)e * (NANT + 1) * maxR;
-    const QResult res = sweep_q<NANT, BLOCK>(base, maxR, R, q, p, red);
+    const auto cols = ColsSel<IDX>::make(base, uidx + (IDX ? (size_t)e * NANT * maxR : 0), tab_s, maxR, U);
+    const QResult res = sweep_q<NANT, BLOCK>(cols, base + (size_t)NANT * maxR, R, q, p, red);
     if (threadIdx.x == 0) hit[e] = res.hit;
     // exact hit: the reference returns the index and leaves weights[] untouched (FIVEVagConclWeight.c:67-69)
-    if (res.hit == FRIRL_HIP_NO_HIT) sweep_weights<NANT, BLOCK>(base, maxR, R, q, p, res.ws, weights + (size_t)e * maxR);
+    if (res.hit == FRIRL_HIP_NO_HIT) sweep_weights<NANT, BLOCK>(cols, R, q, p, res.ws, weights + (size_t)e * maxR);
 }
 
-template <int NANT, int AMAX, int BLOCK>
+template <int NANT, int AMAX, int BLOCK, bool IDX>
 __global__ __launch_bounds__(BLOCK) void get_best_action_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                                 const double *__restrict__ rb, const int32_t *__restrict__ nrules,
+                                                                 const double *__restrict__ rb, const uint16_t *__restrict__ uidx,
+                                                                 const int32_t *__restrict__ nrules,
                                                                  int maxR, int p, const double *__restrict__ states,
                                                                  const double *__restrict__ action_ve, int A,
                                                                  double *__restrict__ actconc, int32_t *__restrict__ best)
@@ -63,8 +72,10 @@ __global__ __launch_bounds__(BLOCK) void get_best_action_kernel(const double *__
     constexpr int NS = NANT - 1;
     const int e = blockIdx.x;
     const int R = nrules[e];
+    extern __shared__ double tab_s[];
     __shared__ double q_s[NS];
     __shared__ GbaScratch<AMAX, BLOCK> gs;
+    if (IDX) for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x < NS) q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, states[(size_t)e * NS + threadIdx.x]);
     if ((int)threadIdx.x < A) gs.ave[threadIdx.x] = action_ve[threadIdx.x];
     __syncthreads();
@@ -72,13 +83,15 @@ __global__ __launch_bounds__(BLOCK) void get_best_action_kernel(const double *__
 #pragma unroll
     for (int k = 0; k < NS; k++) q[k] = q_s[k];
     const double *base = rb + (size_t)e * (NANT + 1) * maxR;
+    const double *qcol = base + (size_t)NANT * maxR;
+    const auto cols = ColsSel<IDX>::make(base, uidx + (IDX ? (size_t)e * NANT * maxR : 0), tab_s, maxR, U);
     int b;
     if (AMAX > 8) {
         __shared__ BlockRed<BLOCK> red;
         double dummy[NANT] = {};
-        b = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(base, maxR, R, q, dummy, p, A, gs, red, nullptr);
+        b = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(cols, qcol, R, q, dummy, p, A, gs, red, nullptr);
     } else {
-        b = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, R, q, p, A, gs);
+        b = sweep_gba<NANT, AMAX, BLOCK>(cols, qcol, R, q, p, A, gs);
     }
     if ((int)threadIdx.x < A) actconc[(size_t)e * A + threadIdx.x] = gs.actconc[threadIdx.x];
     if (threadIdx.x == 0) best[e] = b;
@@ -105,12 +118,16 @@ extern "C" int five_hip_vag_concl(const frirl_hip_tables *t, const frirl_hip_rul
     if ((rc = check_device())) return rc;
     hipStream_t s = as_stream(stream);
     const bool big = b->E < 256;    // few rule bases: 1024-thread workgroups shorten each sweep
+    const bool idx = !big && frirl::use_uidx(t, b);
+    const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
     switch (t->nant) {
 #define M(N)                                                                                                                   \
     case N:                                                                                                                    \
-        if (big) hipLaunchKernelGGL((frirl::vag_concl_kernel<N, 1024>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, b->rb, \
+        if (big) hipLaunchKernelGGL((frirl::vag_concl_kernel<N, 1024, false>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, b->rb, b->uidx, \
                                     b->nrules, b->maxR, eff_p(t, p), x, conc, hit);                                            \
-        else hipLaunchKernelGGL((frirl::vag_concl_kernel<N, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb,       \
+        else if (idx) hipLaunchKernelGGL((frirl::vag_concl_kernel<N, 256, true>), dim3(b->E), dim3(256), tab, s, t->u, t->ve, t->U, b->rb, b->uidx, \
+                                b->nrules, b->maxR, eff_p(t, p), x, conc, hit);                                                \
+        else hipLaunchKernelGGL((frirl::vag_concl_kernel<N, 256, false>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->uidx,       \
                                 b->nrules, b->maxR, eff_p(t, p), x, conc, hit);                                                \
         break;
         FRIRL_NANT_CASES(M)
@@ -130,12 +147,16 @@ extern "C" int five_hip_vag_concl_weight(const frirl_hip_tables *t, const frirl_
     if ((rc = check_device())) return rc;
     hipStream_t s = as_stream(stream);
     const bool big = b->E < 256;
+    const bool idx = !big && frirl::use_uidx(t, b);
+    const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
     switch (t->nant) {
 #define M(N)                                                                                                                          \
     case N:                                                                                                                           \
-        if (big) hipLaunchKernelGGL((frirl::vag_concl_weight_kernel<N, 1024>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, b->rb, \
+        if (big) hipLaunchKernelGGL((frirl::vag_concl_weight_kernel<N, 1024, false>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, b->rb, b->uidx, \
                                     b->nrules, b->maxR, eff_p(t, p), x, weights, hit);                                                \
-        else hipLaunchKernelGGL((frirl::vag_concl_weight_kernel<N, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb,       \
+        else if (idx) hipLaunchKernelGGL((frirl::vag_concl_weight_kernel<N, 256, true>), dim3(b->E), dim3(256), tab, s, t->u, t->ve, t->U, b->rb, b->uidx, \
+                                b->nrules, b->maxR, eff_p(t, p), x, weights, hit);                                                    \
+        else hipLaunchKernelGGL((frirl::vag_concl_weight_kernel<N, 256, false>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->uidx,       \
                                 b->nrules, b->maxR, eff_p(t, p), x, weights, hit);                                                    \
         break;
         FRIRL_NANT_CASES(M)
@@ -150,12 +171,16 @@ static void launch_gba(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
                        int A, double *actconc, int32_t *best, hipStream_t s)
 {
     const bool big = b->E < 256;
+    const bool idx = !big && frirl::use_uidx(t, b);
+    const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
 #define L(AMAX)                                                                                                                          \
     do {                                                                                                                                 \
-        if (big) hipLaunchKernelGGL((frirl::get_best_action_kernel<N, AMAX, 1024>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U,       \
-                                    b->rb, b->nrules, b->maxR, p, states, action_ve, A, actconc, best);                                  \
-        else hipLaunchKernelGGL((frirl::get_best_action_kernel<N, AMAX, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb,      \
-                                b->nrules, b->maxR, p, states, action_ve, A, actconc, best);                                              \
+        if (big) hipLaunchKernelGGL((frirl::get_best_action_kernel<N, AMAX, 1024, false>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, \
+                                    b->rb, b->uidx, b->nrules, b->maxR, p, states, action_ve, A, actconc, best);                         \
+        else if (idx) hipLaunchKernelGGL((frirl::get_best_action_kernel<N, AMAX, 256, true>), dim3(b->E), dim3(256), tab, s, t->u, t->ve, t->U, b->rb, \
+                                b->uidx, b->nrules, b->maxR, p, states, action_ve, A, actconc, best);                                     \
+        else hipLaunchKernelGGL((frirl::get_best_action_kernel<N, AMAX, 256, false>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, \
+                                b->uidx, b->nrules, b->maxR, p, states, action_ve, A, actconc, best);                                     \
     } while (0)
     if (A <= 4) L(4);
     else if (A <= 8) L(8);

@@ -74,7 +74,7 @@ extern "C" five_hip_mirror *five_hip_mirror_create(int32_t nant, int32_t U, cons
         return nullptr;
     }
     m->t.nant = nant; m->t.U = U; m->t.u = m->d_u; m->t.ve = m->d_ve;
-    m->b.E = 1; m->b.maxR = m->maxR; m->b.rb = m->d_rb; m->b.nrules = m->d_nrules;
+    m->b.E = 1; m->b.maxR = m->maxR; m->b.rb = m->d_rb; m->b.nrules = m->d_nrules; m->b.uidx = nullptr;
     m->R = 0;
     return m;
 }

@@ -19,6 +19,7 @@ struct StepShared {
     double rant[FRIRL_HIP_MAX_NANT];       // grid-snapped antecedents of a would-be new rule
     double ve3[FRIRL_HIP_MAX_NANT];        // their VE values
     double cur_states[FRIRL_HIP_MAX_NANT];
+    unsigned idx3[FRIRL_HIP_MAX_NANT];    // universe indices of the snapped antecedents
     double reward;
     int success;
     int same;
@@ -50,11 +51,11 @@ __device__ __forceinline__ int e_greedy(const frirl_hip_agent &ag, int greedy, u
 // frirl_update_sarsa + update_rules (reference src/frirl/frirl_update_sarsa.c:348-385, :22-143).
 // `qp_known`: Q(s',a') already available (fused step: the greedy sweep produced it, identical
 // operands and order -- SURVEY 7(i)); otherwise it is computed by a sweep over ve2.
-template <int NANT, int BLOCK>
-__device__ int update_sarsa_block(const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ base,
+template <int NANT, int BLOCK, class COLS>
+__device__ int update_sarsa_block(const COLS &cols, const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ base,
                                   int maxR, int32_t *nrules_e, const frirl_hip_agent &ag, StepShared &sh, double reward,
                                   bool qp_known, double qp, int32_t *fus_e, double *rant_e, BlockRed<BLOCK> &red,
-                                  const QResult *rn_known = nullptr)
+                                  const QResult *rn_known = nullptr, uint16_t *uidx_e = nullptr)
 {
     const int R = *nrules_e;
     const int p = ag.p > 0 ? ag.p : NANT;
@@ -64,10 +65,10 @@ __device__ int update_sarsa_block(const double *__restrict__ u, const double *__
     double *qcol = base + (size_t)NANT * maxR;
 
     if (!qp_known) {                                                        // :356  Q(s',a')
-        const QResult rp = sweep_q<NANT, BLOCK>(base, maxR, R, q2, p, red);
+        const QResult rp = sweep_q<NANT, BLOCK>(cols, qcol, R, q2, p, red);
         qp = (rp.hit != FRIRL_HIP_NO_HIT) ? qcol[rp.hit] : rp.vagc / rp.ws;
     }
-    const QResult rn = rn_known ? *rn_known : sweep_q<NANT, BLOCK>(base, maxR, R, q1, p, red);    // :357  Q(s,a)
+    const QResult rn = rn_known ? *rn_known : sweep_q<NANT, BLOCK>(cols, qcol, R, q1, p, red);    // :357  Q(s,a)
     const double qnow = (rn.hit != FRIRL_HIP_NO_HIT) ? qcol[rn.hit] : rn.vagc / rn.ws;
     const double qdiff = ag.alpha * (reward + ag.gamma * qp - qnow);        // :358
     int fus = *fus_e;
@@ -79,7 +80,10 @@ __device__ int update_sarsa_block(const double *__restrict__ u, const double *__
             const int k = threadIdx.x;
             const double r = check_possible_states(sh.q_ant[k], ag.grid_values + (size_t)k * FRIRL_HIP_MAX_GRID, ag.grid_len[k]);
             sh.rant[k] = r;
-            sh.ve3[k] = observe_ve(u, ve, U, k, r);
+            const double *uni = u + (size_t)k * U;
+            const unsigned j = snap_index(uni, U, r, universe_div(uni, U));
+            sh.idx3[k] = j;
+            sh.ve3[k] = ve[(size_t)k * U + j];
         }
         __syncthreads();
         double q3[NANT];
@@ -87,12 +91,13 @@ __device__ int update_sarsa_block(const double *__restrict__ u, const double *__
 #pragma unroll
         for (int k = 0; k < NANT; k++) { q3[k] = sh.ve3[k]; same = same && (q3[k] == q1[k]); }
         QResult rr = rn;                                                    // :370 (same VE point => same sweep result)
-        if (!same) rr = sweep_q<NANT, BLOCK>(base, maxR, R, q3, p, red);
+        if (!same) rr = sweep_q<NANT, BLOCK>(cols, qcol, R, q3, p, red);
         if (rr.hit == FRIRL_HIP_NO_HIT) {                                   // :373-377 append and leave
             if (R >= maxR) return FRIRL_HIP_UPD_FULL;
             const double rconc = rr.vagc / rr.ws;
             if (threadIdx.x < NANT) {
                 base[(size_t)threadIdx.x * maxR + R] = q3[threadIdx.x];      // five_add_rule.c:80-81
+                if (uidx_e) uidx_e[(size_t)threadIdx.x * maxR + R] = (uint16_t)sh.idx3[threadIdx.x];   // five_add_rule.c:76
                 if (rant_e) rant_e[(size_t)threadIdx.x * maxR + R] = sh.rant[threadIdx.x];
             }
             if (threadIdx.x == 0) {
@@ -117,16 +122,16 @@ __device__ int update_sarsa_block(const double *__restrict__ u, const double *__
     } else {
         if (ag.skip_rules == 0) fus = 0;                                    // :70-73
         const int r_skip = fus ? R - 1 : -1;                                // :76,124-126: the just-inserted rule keeps its Q
-        sweep_update<NANT, BLOCK>(base, maxR, R, q1, p, rn.ws, qnow, qdiff, ag.weight_significant, r_skip);   // K6+K7
+        sweep_update<NANT, BLOCK>(cols, qcol, R, q1, p, rn.ws, qnow, qdiff, ag.weight_significant, r_skip);   // K6+K7
         status = FRIRL_HIP_UPD_SPREAD;
     }
     if (threadIdx.x == 0) *fus_e = fus;
     return status;
 }
 
-template <int NANT, int BLOCK>
+template <int NANT, int BLOCK, bool IDX>
 __global__ __launch_bounds__(BLOCK) void update_sarsa_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                              double *__restrict__ rb, int32_t *__restrict__ nrules, int maxR,
+                                                              double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules, int maxR,
                                                               const frirl_hip_agent ag, const frirl_hip_envs ev,
                                                               const double *__restrict__ q_ant, const double *__restrict__ reward,
                                                               const double *__restrict__ cur_q_ant, const uint8_t *__restrict__ active)
@@ -136,8 +141,10 @@ __global__ __launch_bounds__(BLOCK) void update_sarsa_kernel(const double *__res
         if (threadIdx.x == 0 && ev.status) ev.status[e] = FRIRL_HIP_UPD_INACTIVE;
         return;
     }
+    extern __shared__ double tab_s[];
     __shared__ StepShared sh;
     __shared__ BlockRed<BLOCK> red;
+    if (IDX) for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x < NANT) {
         const int k = threadIdx.x;
         const double a = q_ant[(size_t)e * NANT + k], c = cur_q_ant[(size_t)e * NANT + k];
@@ -149,13 +156,15 @@ __global__ __launch_bounds__(BLOCK) void update_sarsa_kernel(const double *__res
     __syncthreads();
     double *base = rb + (size_t)e * (NANT + 1) * maxR;
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
-    const int st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, reward[e], false, 0.0, ev.fus + e, rant_e, red);
+    uint16_t *uidx_e = uidx ? uidx + (size_t)e * NANT * maxR : nullptr;
+    const auto cols = ColsSel<IDX>::make(base, uidx_e, tab_s, maxR, U);
+    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, reward[e], false, 0.0, ev.fus + e, rant_e, red, nullptr, uidx_e);
     if (threadIdx.x == 0 && ev.status) ev.status[e] = st;
 }
 
 // FIVE_add_rule (reference src/five/five_add_rule.c:47-95): one thread per environment.
 __global__ void add_rule_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U, int nant, double *__restrict__ rb,
-                                int32_t *__restrict__ nrules, int maxR, int E, const double *__restrict__ rant,
+                                uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules, int maxR, int E, const double *__restrict__ rant,
                                 const double *__restrict__ rconc, const uint8_t *__restrict__ active, double *__restrict__ rant_store,
                                 int32_t *__restrict__ added)
 {
@@ -168,7 +177,10 @@ __global__ void add_rule_kernel(const double *__restrict__ u, const double *__re
             double *base = rb + (size_t)e * (nant + 1) * maxR;
             for (int k = 0; k < nant; k++) {
                 const double v = rant[(size_t)e * nant + k];
-                base[(size_t)k * maxR + R] = observe_ve(u, ve, U, k, v);
+                const double *uni = u + (size_t)k * U;
+                const unsigned j = snap_index(uni, U, v, universe_div(uni, U));
+                base[(size_t)k * maxR + R] = ve[(size_t)k * U + j];
+                if (uidx) uidx[((size_t)e * nant + k) * maxR + R] = (uint16_t)j;
                 if (rant_store) rant_store[((size_t)e * nant + k) * maxR + R] = v;
             }
             base[(size_t)nant * maxR + R] = rconc[e];
@@ -198,15 +210,18 @@ __global__ void env_step_kernel(const frirl_hip_agent ag, int E, int ns, const d
 }
 
 // frirl_episode(): start of an episode (reference src/frirl/frirl_episode.c:46-82).
-template <int NANT, int AMAX, int BLOCK>
+template <int NANT, int AMAX, int BLOCK, bool IDX>
 __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                               const double *__restrict__ rb, const int32_t *__restrict__ nrules,
+                                                               const double *__restrict__ rb, const uint16_t *__restrict__ uidx,
+                                                               const int32_t *__restrict__ nrules,
                                                                int maxR, const frirl_hip_agent ag, const frirl_hip_envs ev)
 {
     constexpr int NS = NANT - 1;
     const int e = blockIdx.x;
+    extern __shared__ double tab_s[];
     __shared__ double q_s[NS];
     __shared__ GbaScratch<AMAX, BLOCK> gs;
+    if (IDX) for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x < NS) {
         const double v = ev.start_states ? ev.start_states[(size_t)e * NS + threadIdx.x] : ag.values_def[threadIdx.x];   // q_states = states = values_def (:46-48)
         ev.states[(size_t)e * NS + threadIdx.x] = v;
@@ -219,13 +234,15 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 #pragma unroll
     for (int k = 0; k < NS; k++) q[k] = q_s[k];
     const double *base = rb + (size_t)e * (NANT + 1) * maxR;
+    const double *qcol = base + (size_t)NANT * maxR;
+    const auto cols = ColsSel<IDX>::make(base, uidx + (IDX ? (size_t)e * NANT * maxR : 0), tab_s, maxR, U);
     int a0;
     if (AMAX > 8) {
         __shared__ BlockRed<BLOCK> red;
         double dummy[NANT] = {};
-        a0 = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(base, maxR, nrules[e], q, dummy, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, nullptr);   // :78
+        a0 = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(cols, qcol, nrules[e], q, dummy, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, nullptr);   // :78
     } else {
-        a0 = sweep_gba<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);   // :78
+        a0 = sweep_gba<NANT, AMAX, BLOCK>(cols, qcol, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);   // :78
     }
     if (threadIdx.x == 0) {
         const uint32_t epi = ev.episode ? (uint32_t)(ev.episode[e] + 1) : 0u;
@@ -240,10 +257,10 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 }
 
 // frirl_episode(): one step of the loop (reference src/frirl/frirl_episode.c:86-185), fused.
-template <int NANT, int AMAX, int BLOCK>
+template <int NANT, int AMAX, int BLOCK, bool IDX>
 __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                              double *__restrict__ rb, int32_t *__restrict__ nrules, int maxR,
-                                                              const frirl_hip_agent ag, const frirl_hip_envs ev)
+                                                              double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules,
+                                                              int maxR, const frirl_hip_agent ag, const frirl_hip_envs ev)
 {
     constexpr int NS = NANT - 1;
     const int e = blockIdx.x;
@@ -251,9 +268,11 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
         if (threadIdx.x == 0 && ev.status) ev.status[e] = FRIRL_HIP_UPD_INACTIVE;
         return;
     }
+    extern __shared__ double tab_s[];
     __shared__ StepShared sh;
     __shared__ BlockRed<BLOCK> red;
     __shared__ GbaScratch<AMAX, BLOCK> gs;
+    if (IDX) for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x == 0) {
         double s[FRIRL_HIP_MAX_NANT], q[FRIRL_HIP_MAX_NANT];
         for (int i = 0; i < NS; i++) s[i] = ev.states[(size_t)e * NS + i];
@@ -272,13 +291,16 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
 #pragma unroll
     for (int k = 0; k < NS; k++) q[k] = sh.ve2[k];
     double *base = rb + (size_t)e * (NANT + 1) * maxR;
+    const double *qcol = base + (size_t)NANT * maxR;
+    uint16_t *uidx_e = uidx ? uidx + (size_t)e * NANT * maxR : nullptr;
+    const auto cols = ColsSel<IDX>::make(base, uidx_e, tab_s, maxR, U);
     double q1[NANT];
 #pragma unroll
     for (int k = 0; k < NANT; k++) q1[k] = sh.ve1[k];
     QResult rn;
     // one pass over the slab: greedy action for s' (:148) AND Q(s,a) of the pending update (frirl_update_sarsa.c:357)
-    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, &rn)
-                              : sweep_gba_q<NANT, AMAX, BLOCK>(base, maxR, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, rn);
+    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, &rn)
+                              : sweep_gba_q<NANT, AMAX, BLOCK>(cols, qcol, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, rn);
     if (threadIdx.x == 0) {
         const int chosen = e_greedy(ag, ap, (uint32_t)e, ev.episode ? (uint32_t)ev.episode[e] : 0u, (uint32_t)ev.ep_steps[e] + 1u);
         gs.best = chosen;
@@ -290,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
     int st = FRIRL_HIP_UPD_INACTIVE;
     if (!ag.evaluate)                                                                                 // :155 (reduction_state == 0)
-        st = update_sarsa_block<NANT, BLOCK>(u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn);  // :159
+        st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn, uidx_e);  // :159
     if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
     if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.cur_q_ant[threadIdx.x];    // :166-168
     if (threadIdx.x == 0) {
@@ -359,7 +381,7 @@ extern "C" int five_hip_add_rule(const frirl_hip_tables *t, const frirl_hip_rule
     if (!rant || !rconc) { set_error("five_hip_add_rule: NULL rant/rconc"); return FRIRL_HIP_EINVAL; }
     if ((rc = check_device())) return rc;
     hipLaunchKernelGGL(frirl::add_rule_kernel, dim3((b->E + 255) / 256), dim3(256), 0, as_stream(stream), t->u, t->ve, t->U, t->nant, b->rb,
-                       b->nrules, b->maxR, b->E, rant, rconc, active, rant_store, added);
+                       b->uidx, b->nrules, b->maxR, b->E, rant, rconc, active, rant_store, added);
     return check_launch("five_hip_add_rule");
 }
 
@@ -376,12 +398,16 @@ extern "C" int frirl_hip_update_sarsa(const frirl_hip_tables *t, const frirl_hip
     if ((rc = check_device())) return rc;
     hipStream_t s = as_stream(stream);
     const bool big = b->E < 256;
+    const bool idx = !big && frirl::use_uidx(t, b);
+    const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
     switch (t->nant) {
 #define M(N)                                                                                                                              \
     case N:                                                                                                                               \
-        if (big) hipLaunchKernelGGL((frirl::update_sarsa_kernel<N, 1024>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, \
+        if (big) hipLaunchKernelGGL((frirl::update_sarsa_kernel<N, 1024, false>), dim3(b->E), dim3(1024), 0, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
                                     b->maxR, *agent, *envs, q_ant, reward, cur_q_ant, active);                                            \
-        else hipLaunchKernelGGL((frirl::update_sarsa_kernel<N, 256>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,     \
+        else if (idx) hipLaunchKernelGGL((frirl::update_sarsa_kernel<N, 256, true>), dim3(b->E), dim3(256), tab, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
+                                b->maxR, *agent, *envs, q_ant, reward, cur_q_ant, active);                                                \
+        else hipLaunchKernelGGL((frirl::update_sarsa_kernel<N, 256, false>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules,     \
                                 b->maxR, *agent, *envs, q_ant, reward, cur_q_ant, active);                                                \
         break;
         FRIRL_Q_NANT_CASES(M)
@@ -409,10 +435,19 @@ template <int N, int AMAX, int BLOCK, bool BEGIN>
 static void launch_episode_v(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
                              hipStream_t s)
 {
-    if (BEGIN) hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, BLOCK>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,
-                                  b->maxR, *ag, *ev);
-    else hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, BLOCK>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules,
-                            b->maxR, *ag, *ev);
+    const bool idx = BLOCK == 256 && frirl::use_uidx(t, b);      // large rule bases only (use_uidx), never the one-wave variant
+    const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
+    if (BEGIN) {
+        if (idx) hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, BLOCK, true>), dim3(b->E), dim3(BLOCK), tab, s, t->u, t->ve, t->U, b->rb, b->uidx,
+                                    b->nrules, b->maxR, *ag, *ev);
+        else hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, BLOCK, false>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->uidx,
+                                b->nrules, b->maxR, *ag, *ev);
+    } else {
+        if (idx) hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, BLOCK, true>), dim3(b->E), dim3(BLOCK), tab, s, t->u, t->ve, t->U, b->rb, b->uidx,
+                                    b->nrules, b->maxR, *ag, *ev);
+        else hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, BLOCK, false>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->uidx,
+                                b->nrules, b->maxR, *ag, *ev);
+    }
 }
 
 // Workgroup shape: 256 threads per environment for large rule bases (bandwidth); ONE wave per environment while

@@ -8,6 +8,8 @@
 // (fiveq.hip) and by the fused SARSA / episode-step kernels (sarsa.hip).
 #pragma once
 
+#include <stdlib.h>
+
 #include "device_common.h"
 
 namespace frirl {
@@ -89,14 +91,58 @@ __device__ __forceinline__ double2 load_col2(const double *__restrict__ p)
     return v;
 }
 
+// Antecedent-column accessors.  ColsF64 streams the f64 SoA columns (reference layout).  ColsIdx streams the 16-bit
+// universe indices (frirl_hip_rulebases.uidx) and reads the VE values from an LDS copy of the tables: the same
+// doubles (rb[k][r] == ve[k][uidx[k][r]] exactly), a quarter of the antecedent bytes.
+struct ColsF64 {
+    const double *base;   // rb slab of the environment
+    int maxR;
+    __device__ __forceinline__ double2 pair(int k, int r) const { return load_col2(base + (size_t)k * maxR + r); }
+};
+
+struct ColsIdx {
+    const uint16_t *idx;  // uidx slab of the environment
+    const double *tab;    // LDS [nant][U]
+    int maxR, U;
+    __device__ __forceinline__ double2 pair(int k, int r) const
+    {
+        const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(idx + (size_t)k * maxR + r));
+        double2 v;
+        v.x = tab[k * U + (w & 0xFFFFu)];
+        v.y = tab[k * U + (w >> 16)];
+        return v;
+    }
+};
+
+template <bool IDX>
+struct ColsSel;
+template <>
+struct ColsSel<false> {
+    using type = ColsF64;
+    static __device__ __forceinline__ type make(const double *base, const uint16_t *, const double *, int maxR, int) { return ColsF64{base, maxR}; }
+};
+template <>
+struct ColsSel<true> {
+    using type = ColsIdx;
+    static __device__ __forceinline__ type make(const double *, const uint16_t *idx, const double *tab, int maxR, int U) { return ColsIdx{idx, tab, maxR, U}; }
+};
+
+// Host-side choice: stream the 16-bit index mirror when it exists, the LDS table fits next to the kernel's static
+// LDS (<= 48 KiB) and the rule bases are large enough for bandwidth to matter (small bases: the per-workgroup
+// table fill would cost more than it saves).
+static inline bool use_uidx(const frirl_hip_tables *t, const frirl_hip_rulebases *b)
+{
+    return b->uidx && t->U <= 65536 && sizeof(double) * t->nant * (size_t)t->U <= 48 * 1024 && b->maxR > 2048 && !getenv("FRIRL_HIP_NO_UIDX");
+}
+
 // Squared VE distance of two adjacent rules (r, r+1) to the observation q over dims [0, NDIM):
 // dimension-ordered, separate multiply and add (five_rule_distance.c:88-90,171-208).
-template <int NDIM>
-__device__ __forceinline__ void sq_dist2(const double *__restrict__ base, int maxR, int r, const double (&q)[NDIM], double &a0, double &a1)
+template <int NDIM, class COLS>
+__device__ __forceinline__ void sq_dist2(const COLS &cols, int r, const double (&q)[NDIM], double &a0, double &a1)
 {
     double2 v[NDIM];
 #pragma unroll
-    for (int k = 0; k < NDIM; k++) v[k] = load_col2(base + (size_t)k * maxR + r);
+    for (int k = 0; k < NDIM; k++) v[k] = cols.pair(k, r);
     double d0 = q[0] - v[0].x, d1 = q[0] - v[0].y;
     a0 = d0 * d0;
     a1 = d1 * d1;
@@ -119,15 +165,14 @@ struct QResult {
 // FIVE_vag_concl's sweep (reference src/five/FIVEVagConcl.c:64-351 live path): distances, first
 // exact hit, Shepard sums wi = 1/d^p, vagc = sum wi*Q, ws = sum wi (:224-235).  All threads return
 // the same QResult.
-template <int NANT, int BLOCK>
-__device__ QResult sweep_q(const double *__restrict__ base, int maxR, int R, const double (&q)[NANT], int p, BlockRed<BLOCK> &red)
+template <int NANT, int BLOCK, class COLS>
+__device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&q)[NANT], int p, BlockRed<BLOCK> &red)
 {
     unsigned best = FRIRL_HIP_NO_HIT;
     double sv = 0.0, sw = 0.0;
-    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
-        sq_dist2<NANT>(base, maxR, r, q, a0, a1);
+        sq_dist2<NANT>(cols, r, q, a0, a1);
         const double2 c = load_col2(qcol + r);
         if (a0 == 0.0) best = min(best, (unsigned)r);
         else {
@@ -156,14 +201,13 @@ __device__ QResult sweep_q(const double *__restrict__ base, int maxR, int R, con
 // FIVE_vag_concl_weight's second pass (reference src/five/FIVEVagConclWeight.c:125-166, K6):
 // weights[r] = (1/d_r^p) / ws for r < R.  Distances are recomputed (8*nant B/rule re-read) instead
 // of spilling wi[] to HBM and reading it back (16 B/rule).
-template <int NANT, int BLOCK>
-__device__ void sweep_weights(const double *__restrict__ base, int maxR, int R, const double (&q)[NANT], int p, double ws,
-                              double *__restrict__ weights)
+template <int NANT, int BLOCK, class COLS>
+__device__ void sweep_weights(const COLS &cols, int R, const double (&q)[NANT], int p, double ws, double *__restrict__ weights)
 {
     const double iws = 1.0 / ws;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
-        sq_dist2<NANT>(base, maxR, r, q, a0, a1);
+        sq_dist2<NANT>(cols, r, q, a0, a1);
         const double w0 = inv_dist_pow(a0, p) * iws;
         const double w1 = inv_dist_pow(a1, p) * iws;
         if (r + 1 < R) {
@@ -176,15 +220,14 @@ __device__ void sweep_weights(const double *__restrict__ base, int maxR, int R, 
 // update_rules' masked write-back (reference src/frirl/frirl_update_sarsa.c:89-120, K7):
 // rconc[r] = qnow + qdiff * w_r where w_r = wi_r / ws > threshold (strict, ordered compare).
 // `r_skip` (or -1) is left untouched: the just-inserted last rule under skip_rules (:31-33,124-126).
-template <int NANT, int BLOCK>
-__device__ void sweep_update(double *__restrict__ base, int maxR, int R, const double (&q)[NANT], int p, double ws, double qnow,
+template <int NANT, int BLOCK, class COLS>
+__device__ void sweep_update(const COLS &cols, double *__restrict__ qcol, int R, const double (&q)[NANT], int p, double ws, double qnow,
                              double qdiff, double threshold, int r_skip)
 {
-    double *__restrict__ qcol = base + (size_t)NANT * maxR;
     const double iws = 1.0 / ws;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
-        sq_dist2<NANT>(base, maxR, r, q, a0, a1);
+        sq_dist2<NANT>(cols, r, q, a0, a1);
         const double w0 = inv_dist_pow(a0, p) * iws;
         const double w1 = inv_dist_pow(a1, p) * iws;
         if (w0 > threshold && r != r_skip) { const double t = qdiff * w0; qcol[r] = qnow + t; }
@@ -210,8 +253,8 @@ struct GbaScratch {
     int best;
 };
 
-template <int NANT, int AMAX, int BLOCK>
-__device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1], int p, int A,
+template <int NANT, int AMAX, int BLOCK, class COLS>
+__device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1], int p, int A,
                          GbaScratch<AMAX, BLOCK> &s)
 {
     constexpr int NS = NANT - 1;
@@ -219,12 +262,10 @@ __device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const
     unsigned sh[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; av[a] = (a < A) ? s.ave[a] : 0.0; }
-    const double *__restrict__ acol = base + (size_t)NS * maxR;
-    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double s0 = 0.0, s1 = 0.0;
-        if (NS > 0) sq_dist2<(NS > 0 ? NS : 1)>(base, maxR, r, qs, s0, s1);
-        const double2 va = load_col2(acol + r);
+        if (NS > 0) sq_dist2<(NS > 0 ? NS : 1)>(cols, r, qs, s0, s1);
+        const double2 va = cols.pair(NS, r);
         const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
 #pragma unroll
@@ -284,8 +325,8 @@ __device__ int sweep_gba(const double *__restrict__ base, int maxR, int R, const
 // (frirl_episode.c:148 -> :159), so one pass over the slab serves both: 8*(nant+1) B per rule and step
 // instead of twice that.  Per-lane accumulation order and the reduction tree are those of the two separate
 // sweeps, so every result is bit-identical to running them one after the other.
-template <int NANT, int AMAX, int BLOCK>
-__device__ int sweep_gba_q(const double *__restrict__ base, int maxR, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
+template <int NANT, int AMAX, int BLOCK, class COLS>
+__device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
                            const double (&q1)[NANT], int p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres)
 {
     constexpr int NS = NANT - 1;
@@ -295,11 +336,10 @@ __device__ int sweep_gba_q(const double *__restrict__ base, int maxR, int R, con
     for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; av[a] = (a < A) ? s.ave[a] : 0.0; }
     unsigned qbest = FRIRL_HIP_NO_HIT;
     double qv = 0.0, qw = 0.0;
-    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double2 v[NANT];
 #pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = load_col2(base + (size_t)k * maxR + r);
+        for (int k = 0; k < NANT; k++) v[k] = cols.pair(k, r);
         const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
         // (1) Q(s,a): full distance to the pending antecedents
@@ -384,8 +424,8 @@ __device__ int sweep_gba_q(const double *__restrict__ base, int maxR, int R, con
 // columns almost simultaneously, so HBM still sees each rule once (L1/L2 absorb the repeats) while the
 // register footprint drops to AG accumulator pairs.  The optional Q(s,a) sums of the fused episode step are
 // spread over the waves by iteration.  Sums per action are one wave butterfly (deterministic).
-template <int NANT, int AG, int AMAX, int BLOCK, bool WITH_Q>
-__device__ int sweep_gba_wide(const double *__restrict__ base, int maxR, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
+template <int NANT, int AG, int AMAX, int BLOCK, bool WITH_Q, class COLS>
+__device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
                               const double (&q1)[NANT], int p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult *qres)
 {
     constexpr int NS = NANT - 1;
@@ -401,12 +441,11 @@ __device__ int sweep_gba_wide(const double *__restrict__ base, int maxR, int R, 
     for (int j = 0; j < AG; j++) { sv[j] = 0.0; sw[j] = 0.0; sh[j] = FRIRL_HIP_NO_HIT; av[j] = (j < na) ? s.ave[a_begin + j] : 0.0; }
     unsigned qbest = FRIRL_HIP_NO_HIT;
     double qv = 0.0, qw = 0.0;
-    const double *__restrict__ qcol = base + (size_t)NANT * maxR;
     int it = 0;
     for (int r = 2 * lane; r < R; r += 2 * FRIRL_WAVE, it++) {
         double2 v[NANT];
 #pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = load_col2(base + (size_t)k * maxR + r);
+        for (int k = 0; k < NANT; k++) v[k] = cols.pair(k, r);
         const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
         if (WITH_Q && (it % WAVES) == wave) {

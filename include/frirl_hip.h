@@ -80,6 +80,13 @@ typedef struct frirl_hip_rulebases {
     int32_t maxR;            /* capacity per rule base (FIVERB.maxnumofrules)           */
     double *rb;              /* [dev] [E][nant+1][maxR]                                 */
     int32_t *nrules;         /* [dev] [E] FIVERB.numofrules                             */
+    uint16_t *uidx;          /* [dev] [E][nant][maxR] universe index of every antecedent (FIVERB.rseqant_uindex,
+                                src/five/FIVE.h:55), or NULL.  Every stored antecedent is snapped to its universe
+                                (five_add_rule.c:76-81), so rb[e][k][r] == ve[k][uidx[e][k][r]] EXACTLY: when this
+                                2-byte mirror is present the scans stream it (2*nant B/rule instead of 8*nant) and
+                                look the VE values up in an LDS copy of the tables -- bit-identical results, a
+                                quarter of the antecedent traffic.  Appends keep it in sync.  Needs U <= 65536 and
+                                nant*U*8 <= 48 KiB; otherwise the f64 columns are streamed. */
 } frirl_hip_rulebases;
 
 /* ---- runtime ------------------------------------------------------------------------------- */

@@ -86,11 +86,12 @@ class Batch:
         idx = [0] if A == 1 else [(a * (U - 1)) // (A - 1) for a in range(A)]
         return np.ascontiguousarray(self.ve[self.nant - 1, idx]), np.ascontiguousarray(self.u[self.nant - 1, idx])
 
-    def to_device(self, device="cuda"):
+    def to_device(self, device="cuda", compressed=False):
         import torch
         import frirl_amd
+        uidx = torch.from_numpy(self.uidx.astype(np.int16)).to(device) if compressed else None
         return frirl_amd.Problem(torch.from_numpy(np.ascontiguousarray(self.u)).to(device), torch.from_numpy(np.ascontiguousarray(self.ve)).to(device),
-                                 torch.from_numpy(self.rb).to(device), torch.from_numpy(self.nrules).to(device))
+                                 torch.from_numpy(self.rb).to(device), torch.from_numpy(self.nrules).to(device), uidx)
 
 
 def demo_batch(env, episodes, E=1):

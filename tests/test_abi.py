@@ -38,7 +38,7 @@ def test_code_object_is_gfx950(lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(frirl_amd.Tables) == 24 and frirl_amd.Tables.u.offset == 8 and frirl_amd.Tables.ve.offset == 16
-    assert C.sizeof(frirl_amd.RuleBases) == 24 and frirl_amd.RuleBases.rb.offset == 8 and frirl_amd.RuleBases.nrules.offset == 16
+    assert C.sizeof(frirl_amd.RuleBases) == 32 and frirl_amd.RuleBases.rb.offset == 8 and frirl_amd.RuleBases.nrules.offset == 16 and frirl_amd.RuleBases.uidx.offset == 24
 
 
 def test_agent_and_envs_struct_layouts():

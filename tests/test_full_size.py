@@ -171,3 +171,44 @@ def test_run_to_run_determinism():
     for a, b in zip(outs[0], outs[1]):
         assert (a == b).all()
     assert (outs[0][3] == frirl_amd.UPD_SPREAD).any() or (outs[0][3] == frirl_amd.UPD_INSERTED).any()
+
+
+def test_compressed_index_path_is_bit_identical_to_f64_path(monkeypatch):
+    """The 16-bit index mirror (frirl_hip_rulebases.uidx + LDS tables) feeds the kernels the SAME doubles as the f64
+    columns (rb[k][r] == ve[k][uidx[k][r]]): every result must be bit-identical between the two paths, and appends
+    must keep the mirror in sync."""
+    import torch
+    dev = torch.device("cuda", 0)
+    En, Rn = 512, 4096
+
+    def run(no_uidx):
+        if no_uidx:
+            monkeypatch.setenv("FRIRL_HIP_NO_UIDX", "1")
+        else:
+            monkeypatch.delenv("FRIRL_HIP_NO_UIDX", raising=False)
+        prob, agent, envs = frirl_amd.demo_batch("acrobot", En, Rn, Rn + 256, dev, seed=11)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        lo, hi = prob.u[:, 0], prob.u[:, prob.U - 2]
+        x = (lo + (hi - lo) * torch.rand((En, prob.nant), generator=g, device="cuda", dtype=torch.float64)).contiguous()
+        x[:64] = envs.rant[:64, :, 77]
+        d, hit = prob.rule_distance(x)
+        conc, hitq = prob.vag_concl(x)
+        w, hitw = prob.vag_concl_weight(x)
+        actconc, best = prob.get_best_action(x[:, : prob.nant - 1].contiguous(), agent.action_ve)
+        frirl_amd.episode_begin(prob, agent, envs)
+        frirl_amd.episode_steps(prob, agent, envs, 8)
+        torch.cuda.synchronize()
+        return prob, envs, [d[:, :Rn].clone(), hit.clone(), conc.clone(), hitq.clone(), torch.nan_to_num(w[:, :Rn], nan=-1.0), hitw.clone(), actconc.clone(),
+                            best.clone(), prob.rb.clone(), prob.nrules.clone(), envs.states.clone(), envs.status.clone()]
+
+    prob_c, envs_c, a = run(no_uidx=False)
+    _, _, b = run(no_uidx=True)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert (x == y).all(), i
+    assert (prob_c.nrules > Rn).any(), "some environments appended rules"
+    # mirror consistency after appends: rb[e][k][r] == ve[k][uidx[e][k][r]] for every live rule
+    idx = prob_c.uidx.long()
+    for k in range(prob_c.nant):
+        gathered = prob_c.ve[k][idx[:, k, :]]
+        live = torch.arange(prob_c.maxR, device=dev)[None, :] < prob_c.nrules[:, None]
+        assert (gathered[live] == prob_c.rb[:, k, :][live]).all(), k

@@ -12,9 +12,9 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-def run_case(b, x, materialise=True):
+def run_case(b, x, materialise=True, compressed=False):
     import torch
-    prob = b.to_device()
+    prob = b.to_device(compressed=compressed)
     xd = torch.from_numpy(x).cuda()
     d, hit = prob.rule_distance(xd, materialise=materialise)
     torch.cuda.synchronize()
@@ -49,6 +49,15 @@ def test_rule_distance_bit_exact(nant, U, R, E, A):
         assert (bits(d[e, :n]) == bits(d_ref[e, :n])).all(), f"env {e}: distances must be bit-identical"
     _, hit2 = run_case(b, x, materialise=False)
     assert (hit2 == hit).all(), "index-only form"
+    if nant * U * 8 <= 48 * 1024:
+        # compressed-antecedent form (16-bit universe indices + LDS tables): the same bits
+        dc, hitc = run_case(b, x, compressed=True)
+        assert (hitc == hit).all()
+        for e in range(E):
+            n = int(b.nrules[e])
+            assert (bits(dc[e, :n]) == bits(d_ref[e, :n])).all(), f"env {e}: compressed form must be bit-identical too"
+        _, hitc2 = run_case(b, x, materialise=False, compressed=True)
+        assert (hitc2 == hit).all()
 
 
 def test_duplicate_zero_distance_rules_lowest_index_wins():
