@@ -198,12 +198,21 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
     const size_t tab_bytes = sizeof(double) * NANT * (size_t)t->U;
     if (b->uidx && t->U <= 65536 && tab_bytes <= 48 * 1024 && !getenv("FRIRL_HIP_NO_UIDX")) {
         constexpr int UI = (NANT <= 8) ? 4 : 2;
-        if (ruledists)
-            hipLaunchKernelGGL((rule_distance_idx_kernel<NANT, true, UI>), grid, dim3(FRIRL_BLOCK), tab_bytes, s, t->u, t->ve, t->U, b->uidx,
-                               b->nrules, b->maxR, x, ruledists, hit, rules_per_block);
-        else
-            hipLaunchKernelGGL((rule_distance_idx_kernel<NANT, false, UI>), grid, dim3(FRIRL_BLOCK), tab_bytes, s, t->u, t->ve, t->U, b->uidx,
-                               b->nrules, b->maxR, x, ruledists, hit, rules_per_block);
+        const int un = (NANT <= 5 && rd_tune().unroll) ? rd_tune().unroll : UI;      // tuning hook (experiments only)
+#define VI(U_)                                                                                                                               \
+    do {                                                                                                                                     \
+        if (ruledists)                                                                                                                       \
+            hipLaunchKernelGGL((rule_distance_idx_kernel<NANT, true, U_>), grid, dim3(FRIRL_BLOCK), tab_bytes, s, t->u, t->ve, t->U, b->uidx, \
+                               b->nrules, b->maxR, x, ruledists, hit, rules_per_block);                                                      \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((rule_distance_idx_kernel<NANT, false, U_>), grid, dim3(FRIRL_BLOCK), tab_bytes, s, t->u, t->ve, t->U, b->uidx, \
+                               b->nrules, b->maxR, x, ruledists, hit, rules_per_block);                                                      \
+    } while (0)
+        if (NANT <= 5 && un == 8) VI(8);
+        else if (NANT <= 5 && un == 2) VI(2);
+        else if (NANT <= 5 && un == 1) VI(1);
+        else VI(UI);
+#undef VI
         return frirl_host::check_launch("five_hip_rule_distance(uidx)");
     }
     const RdTune tn = rd_tune();
