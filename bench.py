@@ -173,6 +173,12 @@ def main():
 
     # ---- leg 1 (the metric): rule-distance sweep, distances materialised ---------------------------------
     dt, kern_ms = timed(lambda: prob.rule_distance(x, ruledists=dists, hit=hit, stream=stream), args.steps, args.warmup)
+    f64_ms = None
+    if prob.uidx is not None and not os.environ.get("FRIRL_HIP_NO_UIDX"):
+        # the same sweep on the reference's f64 SoA columns (no index mirror), timed beside the default path
+        os.environ["FRIRL_HIP_NO_UIDX"] = "1"
+        _, f64_ms = timed(lambda: prob.rule_distance(x, ruledists=dists, hit=hit, stream=stream), max(args.steps // 2, 5), 3)
+        del os.environ["FRIRL_HIP_NO_UIDX"]
     nhits = torch.tensor([float((hit >= 0).sum().item())], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(nhits)
@@ -241,6 +247,10 @@ def main():
                                   "effect, not bandwidth: the kernel streams moved_bytes_per_launch (2*nant B read + 8 B written per eval), "
                                   "moved_GBps / moved_frac is its real HBM rate") if compressed else "f64 layout: contract bytes == moved bytes"},
         }
+        if f64_ms:
+            out["roofline"]["f64_layout"] = {"kernel": "rule_distance_kernel", "avg_launch_ms": f64_ms, "evals_per_s": float(E) * R / (f64_ms * 1e-3),
+                                             "achieved": alg_bytes / (f64_ms * 1e-3) / 1e9, "frac": alg_bytes / (f64_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "note": "same sweep streaming the reference's f64 columns (contract bytes == moved bytes)"}
         if env_leg:
             out["env_steps"] = env_leg
         if learn_leg:
