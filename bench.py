@@ -79,7 +79,20 @@ def cpu_baseline(w):
         t0 = time.time()
         out = subprocess.run([harness, "bench", str(nant), str(U), str(R), str(nq)], check=True, capture_output=True, text=True).stdout
         rec = json.loads(out.strip().splitlines()[-1])
+        # the reference's own parallel model is one private rule base per agent/core (frirl_agent.c:309-325): run one
+        # harness process per host core at the same time (shorter sample) and add the rates up
+        ncores = max(1, min(len(os.sched_getaffinity(0)), 16))    # the GPU box gives one GPU a 16-core share
+        procs = [subprocess.Popen([harness, "bench", str(nant), str(U), str(R), str(max(64, nq // 4))], stdout=subprocess.PIPE, text=True)
+                 for _ in range(ncores)]
+        allc = 0.0
+        for pr in procs:
+            o, _ = pr.communicate()
+            try:
+                allc += json.loads(o.strip().splitlines()[-1])["rule_distance_evals_per_s"]
+            except (ValueError, IndexError):
+                pass
         return dict(value=rec["rule_distance_evals_per_s"], unit="rule-distance evals/s", cores=1, kind="reference",
+                    all_cores={"value": allc, "cores": ncores, "how": "one independent reference process per host core, run concurrently"},
                     sample=f"genuine reference five_rule_distance (AVX2 inline-asm path), one rule base nant={nant} R={R}, {nq} random queries "
                            f"({nq * R:.3g} evals, {rec['rule_distance_s']:.1f} s); vag_concl {rec['vag_concl_evals_per_s']:.3g} evals/s",
                     wall_s=round(time.time() - t0, 1))
