@@ -82,6 +82,7 @@ SIGNATURES = {
     "frirl_hip_episode_begin": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
     "frirl_hip_episode_step": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p]),
     "frirl_hip_episode_steps": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_int32, C.c_void_p]),
+    "frirl_hip_episode_run": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_int32, C.c_int32, C.c_void_p]),
     "frirl_hip_convergence_init": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(ConvergenceDesc), C.c_void_p]),
     "frirl_hip_convergence_update": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
                                                C.c_void_p]),
@@ -344,6 +345,16 @@ def episode_steps(problem, agent, envs, nsteps, stream=None):
                                         _stream(stream)), "frirl_hip_episode_steps")
 
 
+def episode_run(problem, agent, envs, nsteps, lds_rules, stream=None):
+    """frirl_hip_episode_run: up to nsteps steps per environment in ONE launch, rule bases resident in LDS."""
+    check(lib().frirl_hip_episode_run(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), nsteps, lds_rules,
+                                      _stream(stream)), "frirl_hip_episode_run")
+
+
+def can_run_persistent(problem, agent):
+    return agent.A <= 8 and 2 * 8 * problem.nant * problem.U <= 16 * 1024
+
+
 class Convergence:
     """Device-resident construct-loop bookkeeping (struct frirl_hip_convergence)."""
 
@@ -365,7 +376,7 @@ class Convergence:
                                                  _stream(stream)), "frirl_hip_convergence_update")
 
 
-def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None):
+def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None, persistent=True):
     """Batched construct run: frirl_sequential_run's loop (reference frirl_sequential_run.c:55-165) for E agents
     at once.  Episodes run until every environment's rule base is "considered complete" or max_episodes-1 episodes
     have run (:51,59).  Converged environments are masked out of later episodes.  Returns the Convergence object."""
@@ -376,6 +387,14 @@ def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=No
         episode_begin(problem, agent, envs)
         envs.done.copy_(torch.maximum(envs.done, conv.converged))       # converged agents sit this episode out
         steps = 0
+        if persistent and can_run_persistent(problem, agent):
+            # small rule bases: the whole episode in one launch out of LDS; an environment whose rule base outgrows
+            # the LDS slab comes back not-done (status FULL) and finishes through the step kernel below
+            need = int(problem.nrules.max().item()) + 128
+            if need <= 1024:
+                episode_run(problem, agent, envs, max_steps, 256 if need <= 256 else (512 if need <= 512 else 1024))
+                if bool((envs.done != 0).all()):
+                    steps = max_steps
         while steps < max_steps:
             n = min(check_every, max_steps - steps)
             episode_steps(problem, agent, envs, n)

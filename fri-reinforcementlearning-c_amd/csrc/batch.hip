@@ -127,6 +127,22 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
     hipLaunchKernelGGL(frirl::mask_converged_kernel, dim3((b->E + 255) / 256), dim3(256), 0, b->s, b->d_done, b->d_converged, b->E);
     const int chunk = 64;
     int32_t running = 1;
+    // small rule bases: whole episode in one launch out of LDS (frirl_hip_episode_run); environments that outgrow the
+    // LDS slab come back not-done and finish through the step kernel below
+    if (b->agent.A <= 8 && 2 * sizeof(double) * b->nant * (size_t)b->U <= 16 * 1024) {
+        b->h_i.resize(b->E);
+        BCHK(hipMemcpyAsync(b->h_i.data(), b->d_nrules, sizeof(int32_t) * b->E, hipMemcpyDeviceToHost, b->s), "nrules download");
+        BCHK(hipStreamSynchronize(b->s), "nrules sync");
+        int need = 0;
+        for (int e = 0; e < b->E; e++) if (b->h_i[e] > need) need = b->h_i[e];
+        need += 128;
+        if (need <= 1024) {
+            if ((rc = frirl_hip_episode_run(&b->t, &b->rb, &b->agent, &b->envs, b->agent.max_steps, need <= 256 ? 256 : (need <= 512 ? 512 : 1024), b->s))) return rc;
+            hipLaunchKernelGGL(frirl::count_running_kernel, dim3(1), dim3(256), 0, b->s, b->d_done, b->E, b->d_episodes + b->E);
+            BCHK(hipMemcpyAsync(&running, b->d_episodes + b->E, sizeof(int32_t), hipMemcpyDeviceToHost, b->s), "running download");
+            BCHK(hipStreamSynchronize(b->s), "episode sync");
+        }
+    }
     for (int done_steps = 0; done_steps < b->agent.max_steps && running > 0; done_steps += chunk) {
         const int nst = (b->agent.max_steps - done_steps < chunk) ? b->agent.max_steps - done_steps : chunk;
         if ((rc = frirl_hip_episode_steps(&b->t, &b->rb, &b->agent, &b->envs, nst, b->s))) return rc;

@@ -324,6 +324,119 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     }
 }
 
+
+// Persistent episode kernel for SMALL rule bases (the demos' real learning regime: <= 367 rules).
+// One wave owns one environment for up to `nsteps` consecutive steps: the rule base slab, the universes / VE
+// tables, the grids and the episode state are copied into LDS once and every step runs out of LDS -- no global
+// round trip per step (the step kernel pays ~20 dependent global accesses, ~25 us per step).  Appends go to LDS and
+// are written back with the rest of the slab when the wave leaves (episode end, nsteps exhausted, or the LDS slab
+// full: then status = FRIRL_HIP_UPD_FULL with done == 0 and the caller continues with the step kernel).
+// Arithmetic, lane mapping and reduction order are those of the one-wave step kernel => bit-identical results.
+template <int NANT, int AMAX, int CAP>
+__global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+                                                                  double *__restrict__ rb, int32_t *__restrict__ nrules, int maxR,
+                                                                  const frirl_hip_agent ag, const frirl_hip_envs ev, int nsteps)
+{
+    constexpr int NS = NANT - 1, BLOCK = FRIRL_WAVE;
+    const int e = blockIdx.x;
+    if (ev.done[e]) {
+        if (threadIdx.x == 0 && ev.status) ev.status[e] = FRIRL_HIP_UPD_INACTIVE;
+        return;
+    }
+    extern __shared__ double dyn_s[];                  // [2][NANT][U] universes, vague environments
+    __shared__ double slab_s[(NANT + 1) * CAP];        // rule base: antecedent VE columns + consequents
+    __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
+    __shared__ StepShared sh;
+    __shared__ BlockRed<BLOCK> red;
+    __shared__ GbaScratch<AMAX, BLOCK> gs;
+    __shared__ double states_s[FRIRL_HIP_MAX_NANT];
+    __shared__ int32_t nrules_s, fus_s, done_s, steps_s, status_s;
+    __shared__ double reward_s;
+    double *u_s = dyn_s, *ve_s = dyn_s + NANT * U;
+    double *base_g = rb + (size_t)e * (NANT + 1) * maxR;
+    const int R0 = nrules[e];
+    if (R0 > CAP) {                                    // does not fit: leave everything to the step kernel
+        if (threadIdx.x == 0 && ev.status) ev.status[e] = FRIRL_HIP_UPD_FULL;
+        return;
+    }
+    for (int i = threadIdx.x; i < NANT * U; i += BLOCK) { u_s[i] = u[i]; ve_s[i] = ve[i]; }
+    for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += BLOCK) grid_s[i] = ag.grid_values[i];
+    for (int k = 0; k <= NANT; k++)
+        for (int r = threadIdx.x; r < CAP; r += BLOCK) slab_s[k * CAP + r] = (r < R0) ? base_g[(size_t)k * maxR + r] : 0.0;
+    if ((int)threadIdx.x < ag.A) gs.ave[threadIdx.x] = ag.action_ve[threadIdx.x];
+    if (threadIdx.x < NS) states_s[threadIdx.x] = ev.states[(size_t)e * NS + threadIdx.x];
+    if (threadIdx.x < NANT) sh.q_ant[threadIdx.x] = ev.q_ant[(size_t)e * NANT + threadIdx.x];
+    if (threadIdx.x == 0) {
+        nrules_s = R0; fus_s = ev.fus[e]; done_s = 0; steps_s = ev.ep_steps[e]; reward_s = ev.ep_reward[e]; status_s = FRIRL_HIP_UPD_INACTIVE;
+    }
+    frirl_hip_agent agl = ag;
+    agl.grid_values = grid_s;
+    const uint32_t episode = ev.episode ? (uint32_t)ev.episode[e] : 0u;
+    double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
+    const ColsLds cols{slab_s, CAP};
+    double *qcol = slab_s + (size_t)NANT * CAP;
+    const int p = ag.p > 0 ? ag.p : NANT;
+    __syncthreads();
+
+    for (int it = 0; it < nsteps; it++) {
+        if (threadIdx.x == 0) {
+            double q[FRIRL_HIP_MAX_NANT];
+            env_do_action(ag.env_kind, sh.q_ant[NS], states_s, sh.cur_states);                        // frirl_episode.c:97
+            env_get_reward(ag.env_kind, sh.cur_states, sh.reward, sh.success);                        // :106
+            env_quantize(ag.env_kind, NS, grid_s, ag.grid_len, ag.grid_div, sh.cur_states, q);       // :112
+            for (int i = 0; i < NS; i++) sh.cur_q_ant[i] = q[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < NANT) sh.ve1[threadIdx.x] = observe_ve(u_s, ve_s, U, threadIdx.x, sh.q_ant[threadIdx.x]);
+        if (threadIdx.x < NS) sh.ve2[threadIdx.x] = observe_ve(u_s, ve_s, U, threadIdx.x, sh.cur_q_ant[threadIdx.x]);
+        __syncthreads();
+        double q[NS], q1[NANT];
+#pragma unroll
+        for (int k = 0; k < NS; k++) q[k] = sh.ve2[k];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) q1[k] = sh.ve1[k];
+        QResult rn;
+        const int ap = sweep_gba_q<NANT, AMAX, BLOCK>(cols, qcol, nrules_s, q, q1, p, ag.A, gs, red, rn);   // :148 + frirl_update_sarsa.c:357
+        if (threadIdx.x == 0) {
+            const int chosen = e_greedy(ag, ap, (uint32_t)e, episode, (uint32_t)steps_s + 1u);
+            gs.best = chosen;
+            sh.cur_q_ant[NS] = grid_s[NS * FRIRL_HIP_MAX_GRID + chosen];                               // :151
+            sh.ve2[NS] = gs.ave[chosen];
+        }
+        __syncthreads();
+        const double qp = gs.actconc[gs.best];
+        int st = FRIRL_HIP_UPD_INACTIVE;
+        if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr);
+        __syncthreads();
+        if (st == FRIRL_HIP_UPD_INSERTED && rant_e && threadIdx.x < NANT) rant_e[(size_t)threadIdx.x * maxR + (nrules_s - 1)] = sh.rant[threadIdx.x];
+        if (st == FRIRL_HIP_UPD_FULL) {                // LDS slab full: hand the (unchanged) step back to the caller
+            if (threadIdx.x == 0) status_s = FRIRL_HIP_UPD_FULL;
+            __syncthreads();
+            break;
+        }
+        if (threadIdx.x < NS) states_s[threadIdx.x] = sh.cur_states[threadIdx.x];                     // :163-165
+        if (threadIdx.x < NANT) sh.q_ant[threadIdx.x] = sh.cur_q_ant[threadIdx.x];                    // :166-168
+        if (threadIdx.x == 0) {
+            steps_s = steps_s + 1;                                                                    // :174
+            reward_s = reward_s + sh.reward;                                                          // :107
+            status_s = st;
+            if (sh.success == 1 || steps_s >= ag.max_steps) done_s = 1;                               // :183, :86
+        }
+        __syncthreads();
+        if (done_s) break;
+    }
+    // write back: grown / updated slab, episode state
+    const int R1 = nrules_s;
+    for (int k = 0; k <= NANT; k++)
+        for (int r = threadIdx.x; r < R1; r += BLOCK) base_g[(size_t)k * maxR + r] = slab_s[k * CAP + r];
+    if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = states_s[threadIdx.x];
+    if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.q_ant[threadIdx.x];
+    if (threadIdx.x == 0) {
+        nrules[e] = R1; ev.fus[e] = fus_s; ev.done[e] = done_s; ev.ep_steps[e] = steps_s; ev.ep_reward[e] = reward_s;
+        if (ev.status) ev.status[e] = status_s;
+    }
+}
+
 // frirl_sequential_run's construct-loop bookkeeping (reference src/frirl/frirl_sequential_run.c:68-72,83-148),
 // one workgroup per environment.
 __global__ __launch_bounds__(256) void convergence_kernel(const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
@@ -536,4 +649,33 @@ extern "C" int frirl_hip_convergence_update(const frirl_hip_rulebases *b, int na
     if (!agent || !envs || !envs->ep_steps || !envs->ep_reward) { set_error("frirl_hip_convergence_update: NULL agent/envs"); return FRIRL_HIP_EINVAL; }
     hipLaunchKernelGGL(frirl::convergence_kernel, dim3(b->E), dim3(256), 0, as_stream(stream), b->rb, b->nrules, b->maxR, nant, *agent, *envs, *c, 0);
     return check_launch("frirl_hip_convergence_update");
+}
+
+template <int N, int AMAX>
+static void launch_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev, int nsteps,
+                       int lds_rules, hipStream_t s)
+{
+    const size_t dyn = 2 * sizeof(double) * t->nant * (size_t)t->U;
+#define RUN(CAP_) hipLaunchKernelGGL((frirl::episode_run_kernel<N, AMAX, CAP_>), dim3(b->E), dim3(FRIRL_WAVE), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, \
+                                     b->maxR, *ag, *ev, nsteps)
+    if (lds_rules <= 256) RUN(256);
+    else if (lds_rules <= 512) RUN(512);
+    else RUN(1024);
+#undef RUN
+}
+
+extern "C" int frirl_hip_episode_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                                     const frirl_hip_envs *envs, int32_t nsteps, int32_t lds_rules, void *stream)
+{
+    int rc = check_episode(t, b, agent, envs, "frirl_hip_episode_run");
+    if (rc) return rc;
+    if (agent->A > 8 || lds_rules < 2 || lds_rules > 1024 || 2 * sizeof(double) * t->nant * (size_t)t->U > 16 * 1024) {
+        set_error("frirl_hip_episode_run: needs A <= 8, lds_rules <= 1024 and universes/VE tables <= 16 KiB (got A=%d, lds_rules=%d, nant*U=%d)",
+                  agent->A, lds_rules, t->nant * t->U);
+        return FRIRL_HIP_EINVAL;
+    }
+    hipStream_t s = as_stream(stream);
+    if (t->nant == 3) { if (agent->A <= 4) launch_run<3, 4>(t, b, agent, envs, nsteps, lds_rules, s); else launch_run<3, 8>(t, b, agent, envs, nsteps, lds_rules, s); }
+    else { if (agent->A <= 4) launch_run<5, 4>(t, b, agent, envs, nsteps, lds_rules, s); else launch_run<5, 8>(t, b, agent, envs, nsteps, lds_rules, s); }
+    return check_launch("frirl_hip_episode_run");
 }

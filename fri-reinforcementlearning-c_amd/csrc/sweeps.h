@@ -114,6 +114,13 @@ struct ColsIdx {
     }
 };
 
+// rule base resident in LDS (persistent episode kernel): plain 16-byte reads of the workgroup's own slab copy
+struct ColsLds {
+    const double *base;   // LDS [nant+1][cap]
+    int cap;
+    __device__ __forceinline__ double2 pair(int k, int r) const { return *reinterpret_cast<const double2 *>(base + (size_t)k * cap + r); }
+};
+
 template <bool IDX>
 struct ColsSel;
 template <>

@@ -228,6 +228,15 @@ int frirl_hip_episode_step(const frirl_hip_tables *t, const frirl_hip_rulebases 
 int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                             const frirl_hip_envs *envs, int32_t nsteps, void *stream);
 
+/* Persistent form for SMALL rule bases (the demos' learning regime): one wave keeps its environment's rule base,
+ * the tables and the episode state in LDS and runs up to nsteps consecutive steps without a global round trip per
+ * step; results are bit-identical to nsteps calls of frirl_hip_episode_step.  lds_rules (<= 1024) is the LDS slab
+ * capacity: an environment whose rule base does not fit, or fills the slab while appending, stops with status
+ * FRIRL_HIP_UPD_FULL and done == 0 -- continue it with frirl_hip_episode_step(s).  Needs A <= 8 and
+ * 2*nant*U*8 <= 16 KiB (mountaincar, acrobot). */
+int frirl_hip_episode_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                          const frirl_hip_envs *envs, int32_t nsteps, int32_t lds_rules, void *stream);
+
 /* ---- construct-loop bookkeeping of frirl_sequential_run (reference src/frirl/frirl_sequential_run.c:55-165),
  *      per environment: after an episode, converged[e] = same #rules, #steps and reward as the previous episode,
  *      reward > reward_good_above and no consequent moved by >= qdiff_final_tolerance (:83-148); then the

@@ -102,3 +102,45 @@ def test_evaluation_mode_rollout(env):
     assert (prob.rb == before).all() and (prob.nrules == nr).all(), "evaluation must not touch the rule bases"
     assert (envs.ep_steps == fr.ep_steps).all(), (envs.ep_steps.tolist(), fr.ep_steps)
     assert (envs.ep_reward == fr.ep_reward).all()
+
+
+@pytest.mark.parametrize("env", ["mountaincar", "acrobot"])
+def test_persistent_episode_kernel_is_bit_identical_to_step_kernel(env):
+    """frirl_hip_episode_run (rule base, tables and episode state resident in LDS, many steps per launch) must give
+    exactly the bits of the same number of frirl_hip_episode_step launches -- including environments that outgrow the
+    LDS slab (status FULL, continued by the step kernel)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    E = 64
+
+    def run(persistent, lds_rules=256):
+        prob, agent, envs = frirl_amd.demo_fresh_batch(env, E, 1024, dev)
+        for ep in range(5):
+            frirl_amd.episode_begin(prob, agent, envs)
+            if persistent:
+                frirl_amd.episode_run(prob, agent, envs, agent.desc.max_steps, lds_rules)
+                torch.cuda.synchronize()
+                if not bool((envs.done != 0).all()):              # slab full somewhere: finish with the step kernel
+                    assert (envs.status[envs.done == 0] == frirl_amd.UPD_FULL).all()
+                    frirl_amd.episode_steps(prob, agent, envs, agent.desc.max_steps)
+            else:
+                frirl_amd.episode_steps(prob, agent, envs, agent.desc.max_steps)
+            torch.cuda.synchronize()
+            assert (envs.done == 1).all()
+        return [prob.rb.clone(), prob.nrules.clone(), envs.states.clone(), envs.q_ant.clone(), envs.ep_steps.clone(), envs.ep_reward.clone(),
+                envs.fus.clone(), envs.rant.clone()]
+
+    ref = run(False)
+    for lds in (256, 1024):
+        got = run(True, lds)
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert (a == b).all(), (lds, i)
+    assert int(ref[1].max()) > 32
+    if env == "acrobot":
+        # force the overflow path: a 256-rule slab is too small once acrobot's rule base grows past it
+        prob, agent, envs = frirl_amd.demo_fresh_batch(env, 4, 1024, dev)
+        conv = frirl_amd.train(prob, agent, envs, max_episodes=60)
+        prob2, agent2, envs2 = frirl_amd.demo_fresh_batch(env, 4, 1024, dev)
+        conv2 = frirl_amd.train(prob2, agent2, envs2, max_episodes=60, persistent=False)
+        torch.cuda.synchronize()
+        assert (prob.rb == prob2.rb).all() and (prob.nrules == prob2.nrules).all() and int(prob.nrules.max()) > 256
