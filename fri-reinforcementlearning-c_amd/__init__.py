@@ -376,7 +376,7 @@ class Convergence:
                                                  _stream(stream)), "frirl_hip_convergence_update")
 
 
-def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None, persistent=True):
+def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None, persistent=True, persistent_max_rules=256):
     """Batched construct run: frirl_sequential_run's loop (reference frirl_sequential_run.c:55-165) for E agents
     at once.  Episodes run until every environment's rule base is "considered complete" or max_episodes-1 episodes
     have run (:51,59).  Converged environments are masked out of later episodes.  Returns the Convergence object."""
@@ -390,8 +390,10 @@ def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=No
         if persistent and can_run_persistent(problem, agent):
             # small rule bases: the whole episode in one launch out of LDS; an environment whose rule base outgrows
             # the LDS slab comes back not-done (status FULL) and finishes through the step kernel below
+            # (measured: it pays only while the LDS slab is small enough for >= ~12 waves per CU, i.e. the 256-rule slab;
+            #  larger slabs cut the number of resident environments more than they cut the per-step latency)
             need = int(problem.nrules.max().item()) + 128
-            if need <= 1024:
+            if need <= persistent_max_rules:
                 episode_run(problem, agent, envs, max_steps, 256 if need <= 256 else (512 if need <= 512 else 1024))
                 if bool((envs.done != 0).all()):
                     steps = max_steps

@@ -136,7 +136,7 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
         int need = 0;
         for (int e = 0; e < b->E; e++) if (b->h_i[e] > need) need = b->h_i[e];
         need += 128;
-        if (need <= 1024) {
+        if (need <= 256) {      // measured: the LDS-resident form pays only while the slab leaves >= ~12 waves per CU
             if ((rc = frirl_hip_episode_run(&b->t, &b->rb, &b->agent, &b->envs, b->agent.max_steps, need <= 256 ? 256 : (need <= 512 ? 512 : 1024), b->s))) return rc;
             hipLaunchKernelGGL(frirl::count_running_kernel, dim3(1), dim3(256), 0, b->s, b->d_done, b->E, b->d_episodes + b->E);
             BCHK(hipMemcpyAsync(&running, b->d_episodes + b->E, sizeof(int32_t), hipMemcpyDeviceToHost, b->s), "running download");

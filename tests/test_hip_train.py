@@ -139,7 +139,7 @@ def test_persistent_episode_kernel_is_bit_identical_to_step_kernel(env):
     if env == "acrobot":
         # force the overflow path: a 256-rule slab is too small once acrobot's rule base grows past it
         prob, agent, envs = frirl_amd.demo_fresh_batch(env, 4, 1024, dev)
-        conv = frirl_amd.train(prob, agent, envs, max_episodes=60)
+        conv = frirl_amd.train(prob, agent, envs, max_episodes=60, persistent_max_rules=1024)
         prob2, agent2, envs2 = frirl_amd.demo_fresh_batch(env, 4, 1024, dev)
         conv2 = frirl_amd.train(prob2, agent2, envs2, max_episodes=60, persistent=False)
         torch.cuda.synchronize()
