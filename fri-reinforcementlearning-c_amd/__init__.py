@@ -108,6 +108,8 @@ SIGNATURES = {
     "five_hip_mirror_vag_concl_weight": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(C.c_uint32)]),
     "five_hip_mirror_bestact": (C.c_int, [C.c_void_p, _DP, _DP]),
     "five_hip_mirror_get_best_action": (C.c_int, [C.c_void_p, _DP, _DP, C.c_int32, _DP, C.POINTER(C.c_uint32)]),
+    "five_hip_mirror_greedy_step": (C.c_int, [C.c_void_p, C.POINTER(AgentDesc), _DP, C.c_double, _DP, _DP, _DP, C.c_int32, C.POINTER(C.c_uint32), _DP, _DP,
+                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32), _DP, _DP, _DP]),
     "five_hip_mirror_update_sarsa": (C.c_int, [C.c_void_p, C.POINTER(AgentDesc), _DP, C.c_double, _DP, C.POINTER(C.c_int32),
                                                C.POINTER(C.c_int32), _DP, _DP, _DP]),
 }

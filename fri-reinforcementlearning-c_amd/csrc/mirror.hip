@@ -23,6 +23,10 @@ struct five_hip_mirror {
     int32_t *d_ibuf;             // fus, status, done...
     double *h_pin;               // pinned staging
     int32_t *h_ipin;
+    void *h_out, *d_out;         // pinned + device-mapped result block of the fused step (written by the kernel)
+    double *h_rconc, *d_rconc;   // pinned + device-mapped copy of the consequents after the step
+    double grid_sig;             // checksum of the agent grid last uploaded to d_grid
+    int grid_valid;
     int32_t R;                   // host copy of numofrules
     hipStream_t s;
     frirl_hip_tables t;
@@ -36,6 +40,13 @@ struct five_hip_mirror {
     } while (0)
 
 static const int PIN_DOUBLES = 4096;
+
+int frirl_launch_mirror_step(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const double *q_ant, double reward,
+                             const double *cur_q_states, const double *action_ve, const double *action_values, int A, int fus, double *rant_store,
+                             void *out_dev, double *rconc_out_dev, hipStream_t s);
+size_t frirl_mirror_step_out_bytes();
+void frirl_mirror_step_unpack(const void *out_host, int nant, int A, uint32_t *best, double *actconc, double *cur_q_ant, int32_t *fus, int32_t *status,
+                              int32_t *nrules, double *new_rant, double *new_rconc);
 
 namespace frirl {
 __global__ void bestact_kernel(const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR, int nant, int p,
@@ -60,6 +71,9 @@ extern "C" five_hip_mirror *five_hip_mirror_create(int32_t nant, int32_t U, cons
     ok = ok && hipMalloc(&m->d_ibuf, 256) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&m->h_pin, sizeof(double) * PIN_DOUBLES, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&m->h_ipin, 256, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(&m->h_out, frirl_mirror_step_out_bytes(), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&m->d_out, m->h_out, 0) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&m->h_rconc, sizeof(double) * m->maxR, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer((void **)&m->d_rconc, m->h_rconc, 0) == hipSuccess;
     if (ok) {
         ok = hipMemcpyAsync(m->d_u, u, tb, hipMemcpyHostToDevice, m->s) == hipSuccess &&
              hipMemcpyAsync(m->d_ve, ve, tb, hipMemcpyHostToDevice, m->s) == hipSuccess &&
@@ -87,6 +101,8 @@ extern "C" void five_hip_mirror_destroy(five_hip_mirror *m)
     (void)hipFree(m->d_row); (void)hipFree(m->d_grid); (void)hipFree(m->d_rant); (void)hipFree(m->d_ibuf);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
     if (m->h_ipin) (void)hipHostFree(m->h_ipin);
+    if (m->h_out) (void)hipHostFree(m->h_out);
+    if (m->h_rconc) (void)hipHostFree(m->h_rconc);
     if (m->s) (void)hipStreamDestroy(m->s);
     free(m);
 }
@@ -284,5 +300,36 @@ extern "C" int five_hip_mirror_update_sarsa(five_hip_mirror *m, const frirl_hip_
         HIPCHK(hipMemcpyAsync(rconc, m->d_rb + (size_t)n * m->maxR, sizeof(double) * m->R, hipMemcpyDeviceToHost, m->s), "rconc download");
         HIPCHK(hipStreamSynchronize(m->s), "sarsa sync 3");
     }
+    return FRIRL_HIP_OK;
+}
+
+extern "C" int five_hip_mirror_greedy_step(five_hip_mirror *m, const frirl_hip_agent *agent, const double *q_ant, double reward,
+                                           const double *cur_q_states, const double *action_ve, const double *action_values, int32_t A,
+                                           uint32_t *best, double *actconc, double *cur_q_ant, int32_t *fus, int32_t *status, double *new_rant,
+                                           double *new_rconc, double *rconc)
+{
+    if (!m || !agent || !agent->grid_values || !q_ant || !cur_q_states || !action_ve || !action_values || !best || !actconc || !cur_q_ant || !fus || !status ||
+        A < 1 || A > FRIRL_HIP_MAX_ACTIONS) { set_error("five_hip_mirror_greedy_step: bad arguments"); return FRIRL_HIP_EINVAL; }
+    const int n = m->nant;
+    double sig = 0.0;              // the agent's grids change rarely: re-upload only when their checksum does
+    for (int i = 0; i < n * FRIRL_HIP_MAX_GRID; i++) sig += agent->grid_values[i] * (double)(i + 1);
+    for (int k = 0; k < n; k++) sig += 1e6 * agent->grid_len[k] * (k + 1);
+    if (!m->grid_valid || sig != m->grid_sig) {
+        memcpy(m->h_pin + 64, agent->grid_values, sizeof(double) * n * FRIRL_HIP_MAX_GRID);
+        HIPCHK(hipMemcpyAsync(m->d_grid, m->h_pin + 64, sizeof(double) * n * FRIRL_HIP_MAX_GRID, hipMemcpyHostToDevice, m->s), "grid upload");
+        m->grid_sig = sig;
+        m->grid_valid = 1;
+    }
+    frirl_hip_agent ag = *agent;
+    ag.grid_values = m->d_grid;
+    ag.action_ve = nullptr;
+    ag.p = m->p;
+    int rc = frirl_launch_mirror_step(&m->t, &m->b, &ag, q_ant, reward, cur_q_states, action_ve, action_values, A, *fus, m->d_rant, m->d_out, m->d_rconc, m->s);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(m->s), "greedy_step sync");
+    int32_t nr = 0;
+    frirl_mirror_step_unpack(m->h_out, n, A, best, actconc, cur_q_ant, fus, status, &nr, new_rant, new_rconc);
+    m->R = nr;
+    if (rconc && nr) memcpy(rconc, m->h_rconc, sizeof(double) * nr);
     return FRIRL_HIP_OK;
 }

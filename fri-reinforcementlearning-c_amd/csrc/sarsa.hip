@@ -437,6 +437,75 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
     }
 }
 
+
+// ---- single rule base, one launch per environment step (ANSI-C drop-in path) -------------------------------------------
+// Inputs by value in the kernel arguments, outputs written directly into pinned host memory (no staging copies).
+struct MirrorStepArgs {
+    double q_ant[FRIRL_HIP_MAX_NANT];
+    double cur_q_states[FRIRL_HIP_MAX_NANT];
+    double action_ve[FRIRL_HIP_MAX_ACTIONS];
+    double action_values[FRIRL_HIP_MAX_ACTIONS];
+    double reward;
+    int32_t fus;
+    int32_t A;
+};
+
+struct MirrorStepOut {          // layout of the pinned result block
+    double actconc[FRIRL_HIP_MAX_ACTIONS];
+    double cur_q_ant[FRIRL_HIP_MAX_NANT];
+    double new_rant[FRIRL_HIP_MAX_NANT];
+    double new_rconc;
+    int32_t best, fus, status, nrules;
+};
+
+template <int NANT, int AMAX, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void mirror_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+                                                             double *__restrict__ rb, int32_t *__restrict__ nrules, int maxR,
+                                                             const frirl_hip_agent ag, const MirrorStepArgs in, double *__restrict__ rant_store,
+                                                             MirrorStepOut *__restrict__ out, double *__restrict__ rconc_out)
+{
+    constexpr int NS = NANT - 1;
+    __shared__ StepShared sh;
+    __shared__ BlockRed<BLOCK> red;
+    __shared__ GbaScratch<AMAX, BLOCK> gs;
+    __shared__ int32_t fus_s;
+    if (threadIdx.x < NANT) { sh.q_ant[threadIdx.x] = in.q_ant[threadIdx.x]; sh.ve1[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, in.q_ant[threadIdx.x]); }
+    if (threadIdx.x < NS) { sh.cur_q_ant[threadIdx.x] = in.cur_q_states[threadIdx.x]; sh.ve2[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, in.cur_q_states[threadIdx.x]); }
+    if ((int)threadIdx.x < in.A) gs.ave[threadIdx.x] = in.action_ve[threadIdx.x];
+    if (threadIdx.x == 0) fus_s = in.fus;
+    __syncthreads();
+    double q[NS], q1[NANT];
+#pragma unroll
+    for (int k = 0; k < NS; k++) q[k] = sh.ve2[k];
+#pragma unroll
+    for (int k = 0; k < NANT; k++) q1[k] = sh.ve1[k];
+    const ColsF64 cols{rb, maxR};
+    const double *qcol = rb + (size_t)NANT * maxR;
+    const int p = ag.p > 0 ? ag.p : NANT;
+    QResult rn;
+    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(cols, qcol, nrules[0], q, q1, p, in.A, gs, red, &rn)
+                              : sweep_gba_q<NANT, AMAX, BLOCK>(cols, qcol, nrules[0], q, q1, p, in.A, gs, red, rn);
+    if ((int)threadIdx.x < in.A) out->actconc[threadIdx.x] = gs.actconc[threadIdx.x];
+    if (threadIdx.x == 0) {
+        out->best = ap;
+        sh.cur_q_ant[NS] = in.action_values[ap];
+        sh.ve2[NS] = gs.ave[ap];
+    }
+    __syncthreads();
+    if (threadIdx.x < NANT) out->cur_q_ant[threadIdx.x] = sh.cur_q_ant[threadIdx.x];
+    const double qp = gs.actconc[ap];
+    const int R_before = nrules[0];
+    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, rb, maxR, nrules, ag, sh, in.reward, true, qp, &fus_s, rant_store, red, &rn, nullptr);
+    __syncthreads();
+    const int R = (st == FRIRL_HIP_UPD_INSERTED) ? R_before + 1 : R_before;
+    for (int r = threadIdx.x; r < R; r += BLOCK) rconc_out[r] = rb[(size_t)NANT * maxR + r];
+    if (st == FRIRL_HIP_UPD_INSERTED && threadIdx.x < NANT) out->new_rant[threadIdx.x] = sh.rant[threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (st == FRIRL_HIP_UPD_INSERTED) out->new_rconc = rb[(size_t)NANT * maxR + R_before];
+        out->fus = fus_s; out->status = st; out->nrules = R;
+    }
+}
+
 // frirl_sequential_run's construct-loop bookkeeping (reference src/frirl/frirl_sequential_run.c:68-72,83-148),
 // one workgroup per environment.
 __global__ __launch_bounds__(256) void convergence_kernel(const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
@@ -678,4 +747,43 @@ extern "C" int frirl_hip_episode_run(const frirl_hip_tables *t, const frirl_hip_
     if (t->nant == 3) { if (agent->A <= 4) launch_run<3, 4>(t, b, agent, envs, nsteps, lds_rules, s); else launch_run<3, 8>(t, b, agent, envs, nsteps, lds_rules, s); }
     else { if (agent->A <= 4) launch_run<5, 4>(t, b, agent, envs, nsteps, lds_rules, s); else launch_run<5, 8>(t, b, agent, envs, nsteps, lds_rules, s); }
     return check_launch("frirl_hip_episode_run");
+}
+
+// launcher used by mirror.hip (single rule base): see five_hip_mirror_greedy_step
+int frirl_launch_mirror_step(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const double *q_ant, double reward,
+                             const double *cur_q_states, const double *action_ve, const double *action_values, int A, int fus, double *rant_store,
+                             void *out_dev, double *rconc_out_dev, hipStream_t s)
+{
+    frirl::MirrorStepArgs in;
+    memset(&in, 0, sizeof in);
+    memcpy(in.q_ant, q_ant, sizeof(double) * t->nant);
+    memcpy(in.cur_q_states, cur_q_states, sizeof(double) * (t->nant - 1));
+    memcpy(in.action_ve, action_ve, sizeof(double) * A);
+    memcpy(in.action_values, action_values, sizeof(double) * A);
+    in.reward = reward; in.fus = fus; in.A = A;
+    frirl::MirrorStepOut *out = static_cast<frirl::MirrorStepOut *>(out_dev);
+    switch (t->nant) {
+#define M(N)                                                                                                                               \
+    case N:                                                                                                                                \
+        if (A <= 4) hipLaunchKernelGGL((frirl::mirror_step_kernel<N, 4, 256>), dim3(1), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, in, rant_store, out, rconc_out_dev); \
+        else if (A <= 8) hipLaunchKernelGGL((frirl::mirror_step_kernel<N, 8, 256>), dim3(1), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, in, rant_store, out, rconc_out_dev); \
+        else hipLaunchKernelGGL((frirl::mirror_step_kernel<N, 32, 256>), dim3(1), dim3(256), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, in, rant_store, out, rconc_out_dev); \
+        break;
+        FRIRL_Q_NANT_CASES(M)
+#undef M
+        default: set_error("five_hip_mirror_greedy_step: nant=%d outside 2..9", t->nant); return FRIRL_HIP_EINVAL;
+    }
+    return check_launch("five_hip_mirror_greedy_step");
+}
+
+size_t frirl_mirror_step_out_bytes() { return sizeof(frirl::MirrorStepOut); }
+void frirl_mirror_step_unpack(const void *out_host, int nant, int A, uint32_t *best, double *actconc, double *cur_q_ant, int32_t *fus, int32_t *status,
+                              int32_t *nrules, double *new_rant, double *new_rconc)
+{
+    const frirl::MirrorStepOut *o = static_cast<const frirl::MirrorStepOut *>(out_host);
+    *best = (uint32_t)o->best; *fus = o->fus; *status = o->status; *nrules = o->nrules;
+    memcpy(actconc, o->actconc, sizeof(double) * A);
+    memcpy(cur_q_ant, o->cur_q_ant, sizeof(double) * nant);
+    if (new_rant) memcpy(new_rant, o->new_rant, sizeof(double) * nant);
+    if (new_rconc) *new_rconc = o->new_rconc;
 }

@@ -212,6 +212,25 @@ fri_float frirl_check_possible_states(struct frirl_desc *frirl, fri_float observ
 
 /* ---- SARSA update -------------------------------------------------------------------------------- */
 
+/* the agent's hyper-parameters and grids in the HIP layer's form (host pointers) */
+static void dropin_agent(struct frirl_desc *frirl, frirl_hip_agent *ag, double *grid)
+{
+    const int n = frirl->numofantecedents;
+    int k;
+    memset(ag, 0, sizeof *ag);
+    memset(grid, 0, sizeof(double) * FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID);
+    ag->alpha = frirl->alpha; ag->gamma = frirl->gamma;
+    ag->qdiff_pos_boundary = frirl->qdiff_pos_boundary; ag->qdiff_neg_boundary = frirl->qdiff_neg_boundary;
+    ag->weight_significant = frirl->rule_weight_considered_significant_for_update;
+    ag->skip_rules = frirl->skip_rules; ag->p = frirl->fiverb->p; ag->A = frirl->actiondim.values_len;
+    for (k = 0; k < n; k++) {
+        const struct frirl_values_desc *pv = (k < frirl->statedims_len) ? &frirl->possible_states[k] : frirl->possible_actions;
+        ag->grid_len[k] = pv->values_len;
+        memcpy(grid + k * FRIRL_HIP_MAX_GRID, pv->values, sizeof(double) * pv->values_len);
+    }
+    ag->grid_values = grid;
+}
+
 /* reference src/frirl/frirl_update_sarsa.c:348-385: the whole TD step (Q(s',a'), Q(s,a), qdiff, grid snap,
  * append or exact / weighted write-back) is one fused GPU call; the host mirrors its bookkeeping. */
 void frirl_update_sarsa(struct frirl_desc *frirl, fri_float *q_ant, fri_float reward, fri_float *cur_q_ant)
@@ -221,20 +240,9 @@ void frirl_update_sarsa(struct frirl_desc *frirl, fri_float *q_ant, fri_float re
     static double grid[FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID];
     double new_rant[FRIRL_HIP_MAX_NANT], new_rconc = 0.0;
     int32_t fus = (frirl->fus_is_rule_inserted != 0.0), status = 0;
-    const int n = frirl->numofantecedents;
-    int k, rc;
+    int rc;
 
-    memset(&ag, 0, sizeof ag);
-    ag.alpha = frirl->alpha; ag.gamma = frirl->gamma;
-    ag.qdiff_pos_boundary = frirl->qdiff_pos_boundary; ag.qdiff_neg_boundary = frirl->qdiff_neg_boundary;
-    ag.weight_significant = frirl->rule_weight_considered_significant_for_update;
-    ag.skip_rules = frirl->skip_rules; ag.p = frb->p; ag.A = frirl->actiondim.values_len;
-    for (k = 0; k < n; k++) {
-        const struct frirl_values_desc *pv = (k < frirl->statedims_len) ? &frirl->possible_states[k] : frirl->possible_actions;
-        ag.grid_len[k] = pv->values_len;
-        memcpy(grid + k * FRIRL_HIP_MAX_GRID, pv->values, sizeof(double) * pv->values_len);
-    }
-    ag.grid_values = grid;
+    dropin_agent(frirl, &ag, grid);
     rc = five_hip_mirror_update_sarsa(five_dropin_mirror(frb), &ag, q_ant, reward, cur_q_ant, &fus, &status, new_rant, &new_rconc, frb->rconc);
     if (rc) five_dropin_fatal("frirl_update_sarsa", rc);
     if (status == FRIRL_HIP_UPD_INSERTED) five_dropin_note_appended(frb, new_rant, new_rconc);
@@ -271,14 +279,34 @@ void frirl_episode(struct frirl_desc *frirl)
         frirl->get_reward_func(frirl, cur_states, ns, &frirl->reward);
         frirl->reward.ep_total_value += frirl->reward.value;
         frirl->quant_obs_func(frirl, cur_states, ns, cur_q_ant);
-        if (frirl->original_learning == 0) {
-            getActionFromTerminal(frirl);
-            ap = (frirl->keyaction == 32 || frirl->keyaction >= (unsigned int)frirl->actiondim.values_len) ? frirl_e_greedy_selection(frirl, cur_q_ant) : frirl->keyaction;
+        if (frirl->original_learning != 0 && frirl->reduction_state == 0 && (frirl->no_random == 1 || frirl->epsilon == 0.0)) {
+            /* greedy learning step (every shipped demo): frirl_get_best_action (:148) and frirl_update_sarsa (:159) as ONE
+             * GPU launch and one synchronisation; same kernels' arithmetic as the two separate calls */
+            static double grid[FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID];
+            frirl_hip_agent ag;
+            double new_rant[FRIRL_HIP_MAX_NANT], new_rconc = 0.0;
+            int32_t fus = (frirl->fus_is_rule_inserted != 0.0), status = 0;
+            uint32_t best = 0;
+            int rc;
+            dropin_agent(frirl, &ag, grid);
+            rc = five_hip_mirror_greedy_step(five_dropin_mirror(frirl->fiverb), &ag, q_ant, frirl->reward.value, cur_q_ant,
+                                             frirl->possible_actions->vevalues, frirl->actiondim.values, frirl->actiondim.values_len, &best,
+                                             frirl->fgba_actconc, cur_q_ant, &fus, &status, new_rant, &new_rconc, frirl->fiverb->rconc);
+            if (rc) five_dropin_fatal("frirl_episode(greedy step)", rc);
+            if (status == FRIRL_HIP_UPD_INSERTED) five_dropin_note_appended(frirl->fiverb, new_rant, new_rconc);
+            else if (status == FRIRL_HIP_UPD_FULL) fprintf(stderr, "frirl_episode: rule base full (%d rules), new rule dropped\n", frirl->fiverb->numofrules);
+            frirl->fus_is_rule_inserted = (fri_float)fus;
+            ap = best;
         } else {
-            ap = frirl_e_greedy_selection(frirl, cur_q_ant);
+            if (frirl->original_learning == 0) {
+                getActionFromTerminal(frirl);
+                ap = (frirl->keyaction == 32 || frirl->keyaction >= (unsigned int)frirl->actiondim.values_len) ? frirl_e_greedy_selection(frirl, cur_q_ant) : frirl->keyaction;
+            } else {
+                ap = frirl_e_greedy_selection(frirl, cur_q_ant);
+            }
+            cur_q_ant[ns] = frirl->actiondim.values[ap];
+            if (frirl->reduction_state == 0) frirl_update_sarsa(frirl, q_ant, frirl->reward.value, cur_q_ant);
         }
-        cur_q_ant[ns] = frirl->actiondim.values[ap];
-        if (frirl->reduction_state == 0) frirl_update_sarsa(frirl, q_ant, frirl->reward.value, cur_q_ant);
         for (i = 0; i < ns; i++) states[i] = cur_states[i];
         for (i = 0; i < n; i++) q_ant[i] = cur_q_ant[i];
         frirl->reward.ep_total_steps++;

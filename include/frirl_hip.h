@@ -289,6 +289,15 @@ int five_hip_mirror_get_best_action(five_hip_mirror *m, const double *states, co
 int five_hip_mirror_update_sarsa(five_hip_mirror *m, const frirl_hip_agent *agent, const double *q_ant, double reward,
                                  const double *cur_q_ant, int32_t *fus, int32_t *status, double *new_rant, double *new_rconc,
                                  double *rconc);
+/* One greedy environment step of frirl_episode() in ONE launch and ONE synchronisation (reference
+ * src/frirl/frirl_episode.c:148-160): greedy action for the new quantised state (frirl_get_best_action) and the SARSA
+ * update of the pending (q_ant, reward) pair towards it (frirl_update_sarsa).  Inputs travel as kernel arguments, results
+ * are written by the kernel straight into pinned host memory.  cur_q_states host [nant-1], action_ve / action_values host
+ * [A]; outputs: *best, actconc host [A], cur_q_ant host [nant] (state + chosen action), then as five_hip_mirror_update_sarsa. */
+int five_hip_mirror_greedy_step(five_hip_mirror *m, const frirl_hip_agent *agent, const double *q_ant, double reward,
+                                const double *cur_q_states, const double *action_ve, const double *action_values, int32_t A,
+                                uint32_t *best, double *actconc, double *cur_q_ant, int32_t *fus, int32_t *status, double *new_rant,
+                                double *new_rconc, double *rconc);
 
 /* =================================================================================================
  * Batch object, HOST descriptors: E agents of one problem owned by the library (device memory, stream,
