@@ -5,13 +5,20 @@
 // re-reads them; here the two passes are fused in registers, so the only HBM traffic is the
 // compulsory one: 8*nant B read per rule (+ 8 B written when the distances are materialised).
 //
-// Mapping (HBM-bound stream, no reuse => no MFMA, no LDS tiling of the rule data):
+// Mapping (HBM-bound stream, no reuse => no MFMA, no LDS tiling of the rule data, no XCD-aware remap: nothing but
+// the small tables is shared between workgroups):
 //   grid.x = environment, grid.y = rule chunk; 256 threads; every lane loads 16 B (two rules)
-//   from each of the nant SoA columns => 1 KiB per wave-instruction, fully coalesced; UNROLL
-//   independent column sets are issued before the first use so that >= 12 x 16 B loads per lane
-//   are in flight.  The observation's VE values are looked up once per workgroup and staged in
-//   LDS.  First exact hit: per-lane minimum index -> wave butterfly -> LDS -> one integer
-//   atomicMin per workgroup (deterministic; only taken when a hit exists).
+//   from each of the nant SoA columns => 1 KiB per wave-instruction, fully coalesced; UNROLL (8 for
+//   nant <= 5) independent column sets are issued before the first use; loads and stores carry the
+//   non-temporal hint (pure stream).  The observation's VE values are looked up once per workgroup
+//   and staged in LDS.  First exact hit: per-lane minimum index -> wave butterfly -> LDS -> one
+//   integer atomicMin per workgroup (deterministic; only taken when a hit exists).
+// Two layouts, same arithmetic on the same doubles (bit-identical results):
+//   rule_distance_kernel      streams the f64 VE columns (the reference's layout), 0.76 of HBM peak at cfg2;
+//   rule_distance_idx_kernel  streams the 16-bit universe-index mirror and gathers the VE values from an LDS copy
+//                             of the tables: 2*nant B read per rule, ~2x the evaluations per second.
+// Measurements and the A/B log: profiles/r01_rule_distance_tuning.md.  The FRIRL_HIP_RD_* / FRIRL_HIP_NO_UIDX
+// environment variables are experiment hooks (tools/ab_rd.py); unset, the shipped configuration runs.
 #include <stdlib.h>
 
 #include "device_common.h"
