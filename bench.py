@@ -248,6 +248,7 @@ def main():
             "metric": "rule-distance evals/sec (rules x envs)", "value": evals / dt, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "device": torch.cuda.get_device_name(device),
             "config": {"workload": args.workload, "nant": nant, "universe_len": w["U"], "rules_per_env": R, "envs_per_gpu": E,
                        "sharding": f"env ids split over {world} rank(s), no data-path collective; reward statistics all-reduced",
                        "exact_hits": int(nhits.item())},

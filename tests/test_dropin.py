@@ -84,6 +84,15 @@ def test_demo_parity_through_dropin_api(env, steps_rules, built, tmp_path, golde
     r = subprocess.run([demo, "--env", env, "-q"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "converged 1" in r.stdout
+    # every episode's report line (reference frirl_sequential_run.c:77-80) against the genuine reference's trace
+    import json
+    import re
+    eps = [json.loads(l) for l in open(os.path.join(golden_dir, f"ref_{env}.trace.jsonl")) if '"k":"ep"' in l]
+    lines = re.findall(r"Episode: (\d+)\tSteps: (\d+)\tReward: (?:\x1b\[[0-9;]*m)?(-?[0-9.]+)(?:\x1b\[[0-9;]*m)?\tRules: (\d+)", r.stdout)
+    assert len(lines) == len(eps), (len(lines), len(eps))
+    for (n, steps, reward, rules), ref in zip(lines, eps):
+        assert int(n) == ref["ep"] and int(steps) == ref["steps"] and int(rules) == ref["R"], (n, steps, rules, ref)
+        assert abs(float(reward) - float.fromhex(ref["reward"])) <= 1e-6 * max(1.0, abs(float.fromhex(ref["reward"])))
     mine = load_rb(tmp_path / f"{env}.frirlrb.txt")
     ref = load_rb(os.path.join(golden_dir, f"ref_{env}.frirlrb.txt"))
     assert mine.shape == ref.shape and mine.shape[0] == steps_rules
