@@ -53,6 +53,18 @@ class EnvsDesc(C.Structure):
                 ("ep_reward", C.c_void_p), ("rant", C.c_void_p), ("status", C.c_void_p), ("start_states", C.c_void_p), ("episode", C.c_void_p)]
 
 
+class RolloutDesc(C.Structure):
+    """struct frirl_hip_rollout (include/frirl_hip.h)."""
+    _fields_ = [("start_states", C.c_void_p), ("exclude_mask", C.c_void_p), ("rule_slot", C.c_void_p), ("steps", C.c_void_p),
+                ("reward", C.c_void_p), ("success", C.c_void_p), ("final_states", C.c_void_p)]
+
+
+class ReduceResult(C.Structure):
+    """struct frirl_hip_reduce_result (include/frirl_hip.h)."""
+    _fields_ = [("rules_before", C.c_int32), ("rules_after", C.c_int32), ("rounds", C.c_int32), ("rollouts", C.c_int32),
+                ("steps_incremental", C.c_int32), ("reserved", C.c_int32), ("reward", C.c_double)]
+
+
 class ConvergenceDesc(C.Structure):
     """struct frirl_hip_convergence (include/frirl_hip.h)."""
     _fields_ = [("prev_nrules", C.c_void_p), ("prev_steps", C.c_void_p), ("prev_reward", C.c_void_p), ("prev_rconc", C.c_void_p),
@@ -73,6 +85,12 @@ SIGNATURES = {
     "five_hip_vag_concl_weight": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frirl_hip_get_best_action": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "five_hip_vag_concl_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frirl_hip_get_best_action_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frirl_hip_rollout_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_int32, C.POINTER(RolloutDesc), C.c_void_p]),
+    "frirl_hip_reduce_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                          C.POINTER(C.c_int32), C.POINTER(ReduceResult), C.c_void_p]),
     "five_hip_add_rule": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "frirl_hip_update_sarsa": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p,
@@ -222,6 +240,63 @@ class Problem:
         check(lib().frirl_hip_get_best_action(C.byref(self.tables), C.byref(self.bases), p, _ptr(states), _ptr(action_ve), A,
                                               _ptr(actconc), _ptr(best), _stream(stream)), "frirl_hip_get_best_action")
         return actconc, best
+
+    def vag_concl_shared(self, x, p=0, stream=None):
+        """five_hip_vag_concl_shared: Q observations against this ONE rule base (E == 1)."""
+        import torch
+        assert self.E == 1 and x.is_cuda and x.dtype == torch.float64 and x.shape[1] == self.nant and x.is_contiguous()
+        Q = x.shape[0]
+        conc = torch.empty((Q,), dtype=torch.float64, device=x.device)
+        hit = torch.empty((Q,), dtype=torch.int32, device=x.device)
+        check(lib().five_hip_vag_concl_shared(C.byref(self.tables), C.byref(self.bases), p, Q, _ptr(x), _ptr(conc), _ptr(hit), _stream(stream)),
+              "five_hip_vag_concl_shared")
+        return conc, hit
+
+    def get_best_action_shared(self, states, action_ve, p=0, stream=None):
+        """frirl_hip_get_best_action_shared: Q states against this ONE rule base (E == 1)."""
+        import torch
+        assert self.E == 1 and states.is_cuda and states.dtype == torch.float64 and states.shape[1] == self.nant - 1 and states.is_contiguous()
+        Q, A = states.shape[0], action_ve.numel()
+        actconc = torch.empty((Q, A), dtype=torch.float64, device=states.device)
+        best = torch.empty((Q,), dtype=torch.int32, device=states.device)
+        check(lib().frirl_hip_get_best_action_shared(C.byref(self.tables), C.byref(self.bases), p, Q, _ptr(states), _ptr(action_ve), A, _ptr(actconc),
+                                                     _ptr(best), _stream(stream)), "frirl_hip_get_best_action_shared")
+        return actconc, best
+
+    def rollout_shared(self, agent, Q, start_states=None, exclude_mask=None, rule_slot=None, stream=None):
+        """frirl_hip_rollout_shared: Q greedy roll-outs (frirl_test_run's episode) on this ONE rule base (E == 1).
+        Returns (steps[Q] i32, reward[Q] f64, success[Q] i32, final_states[Q][nant-1])."""
+        import torch
+        dev_ = self.rb.device
+        assert self.E == 1
+        ro = RolloutDesc()
+        steps = torch.empty((Q,), dtype=torch.int32, device=dev_)
+        reward = torch.empty((Q,), dtype=torch.float64, device=dev_)
+        success = torch.empty((Q,), dtype=torch.int32, device=dev_)
+        final = torch.empty((Q, self.nant - 1), dtype=torch.float64, device=dev_)
+        if start_states is not None:
+            assert start_states.shape == (Q, self.nant - 1) and start_states.dtype == torch.float64 and start_states.is_contiguous()
+            ro.start_states = _ptr(start_states)
+        if exclude_mask is not None:
+            assert exclude_mask.shape == (Q,) and exclude_mask.dtype == torch.int32 and rule_slot.dtype == torch.uint8 and rule_slot.numel() == self.maxR
+            ro.exclude_mask, ro.rule_slot = _ptr(exclude_mask), _ptr(rule_slot)
+        ro.steps, ro.reward, ro.success, ro.final_states = _ptr(steps), _ptr(reward), _ptr(success), _ptr(final)
+        check(lib().frirl_hip_rollout_shared(C.byref(self.tables), C.byref(self.bases), C.byref(agent.desc), Q, C.byref(ro), _stream(stream)),
+              "frirl_hip_rollout_shared")
+        return steps, reward, success, final
+
+    def reduce_shared(self, agent, strategy, reward_tolerance=0.0, depth=0, rant=None, stream=None):
+        """frirl_hip_reduce_shared: the reference's rule-base reduction as speculative batched try-remove; compacts this
+        ONE rule base in place.  Returns (kept original indices, ReduceResult)."""
+        import numpy as np
+        assert self.E == 1
+        R0 = int(self.nrules[0].item())
+        kept = np.zeros(R0, dtype=np.int32)
+        res = ReduceResult()
+        check(lib().frirl_hip_reduce_shared(C.byref(self.tables), C.byref(self.bases), C.byref(agent.desc), _ptr(rant) if rant is not None else None,
+                                            strategy, reward_tolerance, depth, kept.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(res), _stream(stream)),
+              "frirl_hip_reduce_shared")
+        return kept[: res.rules_after], res
 
     def add_rule(self, rant, rconc, active=None, rant_store=None, stream=None):
         """five_hip_add_rule: appends rant[e] -> rconc[e]; returns added [E] int32."""

@@ -213,4 +213,27 @@ __device__ __forceinline__ double check_possible_states(double obs, const double
     return (rel < rel_next) ? v[i] : v[i + 1];
 }
 
+// Counter-based per-environment random stream: SplitMix64 finaliser over (seed, env, episode, step, draw).
+// Stateless, so the trajectory of environment e does not depend on how environments are sharded over GPUs.
+__device__ __forceinline__ double rng_unit(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step, uint32_t draw)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * ((env << 32) | episode) + 0xD1B54A32D192ED03ULL * (((uint64_t)step << 8) | draw);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// frirl_e_greedy_selection (reference src/frirl/frirl_e_greedy_selection.c:21-37): greedy when no_random == 1 or
+// epsilon == 0 or the draw exceeds epsilon; otherwise a uniformly drawn action (the reference's index can equal A,
+// one past the last action; clamped here -- SURVEY Appendix C "fix in the batched path").
+__device__ __forceinline__ int e_greedy(const frirl_hip_agent &ag, int greedy, uint32_t env, uint32_t episode, uint32_t step)
+{
+    if (ag.no_random == 1 || ag.epsilon == 0.0) return greedy;
+    const uint64_t gid = ag.env_id_base + env;
+    if (rng_unit(ag.seed, gid, episode, step, 0) > ag.epsilon) return greedy;
+    int a = (int)round(rng_unit(ag.seed, gid, episode, step, 1) * ag.A);
+    return a >= ag.A ? ag.A - 1 : a;
+}
+
 }  // namespace frirl

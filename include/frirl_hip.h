@@ -161,6 +161,49 @@ typedef struct frirl_hip_agent {
                                                   GLOBAL environment id, so trajectories do not depend on the sharding */
 } frirl_hip_agent;
 
+/* frirl_test_run's greedy roll-out (reference src/frirl/frirl_test_run.c:66-70 -> frirl_episode with reduction_state == 1,
+ * frirl_episode.c:28-194 without the update at :155) for Q environments sharing ONE read-only rule base: lane =
+ * environment, whole episodes in one launch.  `agent` as for the episode entry points (env_kind, max_steps, grids, action
+ * values / VE points, epsilon-greedy stream keyed by env_id_base + row; alpha/gamma/... unused).
+ * Optional "try-remove" view of the rule base (the replays of the rule-base reduction, frirl_sequential_run.c:170-350):
+ * rule r carries a candidate slot rule_slot[r] (0..31, 255 = not a candidate); environment q ignores every rule whose
+ * slot bit is set in exclude_mask[q] -- bit-identical to running on the rule base compacted by five_remove_rule. */
+typedef struct frirl_hip_rollout {
+    const double *start_states;    /* [dev] [Q][nant-1] or NULL = agent->values_def                       */
+    const uint32_t *exclude_mask;  /* [dev] [Q] or NULL                                                   */
+    const uint8_t *rule_slot;      /* [dev] [maxR] or NULL (together with exclude_mask)                   */
+    int32_t *steps;                /* [dev] [Q] reward.ep_total_steps                                     */
+    double *reward;                /* [dev] [Q] reward.ep_total_value                                     */
+    int32_t *success;              /* [dev] [Q] reward.success of the last step, or NULL                  */
+    double *final_states;          /* [dev] [Q][nant-1] or NULL                                           */
+} frirl_hip_rollout;
+int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, int32_t Q,
+                             const frirl_hip_rollout *ro, void *stream);
+
+/* Rule-base reduction (reference frirl_sequential_run.c:170-350, strategies 1 = smallest |Q| first, 2 = largest |Q|
+ * first) as a batched "try-remove" on the GPU.  The reference tests ONE candidate per replayed episode: remove it, replay
+ * greedily, keep the removal iff the episode still succeeds (reward > agent->reward_good_above) in the same number of
+ * steps with |reward change| <= reward_tolerance, else restore it and never try it again.  Consequents do not change
+ * during the reduction, so the candidate order is known in advance (stable sort by |Q|), and the replays of the next
+ * `depth` candidates can all run at once: one lane per node of the binary accept/reject tree (2^depth - 1 roll-outs per
+ * launch through frirl_hip_rollout_shared's exclude masks); the host then walks the tree along the outcomes that
+ * actually happened.  Same decisions, same surviving rules in the same order as the sequential loop.  Replays are capped
+ * at steps_incremental + 1 steps (a longer episode is rejected anyway, :212).
+ *   b      ONE rule base (E == 1); compacted in place (rb columns, nrules[0], uidx if present)
+ *   rant   [dev] [nant][maxR] raw antecedents compacted alongside, or NULL
+ *   kept   [host] [rules_before] receives the ORIGINAL index of each surviving rule (first rules_after entries), or NULL
+ *   depth  candidates per launch, 1..12 (0 = default 10) */
+typedef struct frirl_hip_reduce_result {
+    int32_t rules_before, rules_after;
+    int32_t rounds;              /* kernel launches after the baseline replay                          */
+    int32_t rollouts;            /* episodes replayed (speculative ones included)                      */
+    int32_t steps_incremental;   /* steps of the un-reduced rule base's episode (:196-198)             */
+    int32_t reserved;
+    double reward;               /* prev_reward after the last accepted removal                        */
+} frirl_hip_reduce_result;
+int frirl_hip_reduce_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, double *rant, int strategy,
+                            double reward_tolerance, int depth, int32_t *kept, frirl_hip_reduce_result *result, void *stream);
+
 /* Per-environment episode state (reference: fields of frirl_desc + frirl_reward_desc that
  * frirl_episode() carries from step to step, src/frirl/frirl_episode.c:28-194). */
 typedef struct frirl_hip_envs {
@@ -186,6 +229,18 @@ typedef struct frirl_hip_convergence {
     int32_t *converged;      /* [dev] [E] 1 once "RB considered complete" (sticky)                        */
     int32_t *episodes;       /* [dev] [E] episodes run until convergence (counts while not converged)     */
 } frirl_hip_convergence;
+
+/* ---- one SHARED, read-only rule base, many observations (evaluation of a trained rule base, e.g.
+ *      frirl_test_run's policy for many environments at once; reference FIVE_vag_concl / frirl_get_best_action
+ *      called Q times on the same FIVERB).  `b` describes ONE rule base (E == 1).  Each lane owns one observation and
+ *      walks the rules in index order through LDS-staged tiles, so the Shepard sums are accumulated sequentially in the
+ *      reference's own order (FIVEVagConcl.c:224-235); the rule tiles are reused by every observation of the workgroup
+ *      (compute-bound, not HBM-bound).
+ *   x [dev][Q][nant] / states [dev][Q][nant-1]; outputs as the per-environment forms, one row per observation */
+int five_hip_vag_concl_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, int p, int32_t Q, const double *x,
+                              double *conc, uint32_t *hit, void *stream);
+int frirl_hip_get_best_action_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, int p, int32_t Q, const double *states,
+                                     const double *action_ve, int A, double *actconc, int32_t *best, void *stream);
 
 /* ---- FIVE_add_rule (reference src/five/five_add_rule.c:47-95) ---------------------------------
  * Appends one rule per environment where active[e] != 0 (active == NULL: all): rb[e][k][R] =

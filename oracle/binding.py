@@ -82,6 +82,7 @@ def lib():
         "orc_frirl_get_fus": (d, [vp]),
         "orc_frirl_set_fus": (None, [vp, d]),
         "orc_frirl_set_max_episodes": (None, [vp, i]),
+        "orc_frirl_set_values_def": (None, [vp, i, C.c_double]),
         "orc_frirl_set_max_steps": (None, [vp, i]),
         "orc_frirl_hash": (u64, [vp]),
         "orc_frirl_total_steps": (C.c_long, [vp]),
@@ -192,6 +193,9 @@ class Five:
     @property
     def maxR(self):
         return self.c.maxR
+
+    def remove_rule(self, r):
+        return lib().orc_remove_rule(self.h, int(r))
 
     def arr(self, name, n):
         return np.ctypeslib.as_array(getattr(self.c, name), shape=(n,))
@@ -354,6 +358,10 @@ class Frirl:
         if max_episodes is not None:
             lib().orc_frirl_set_max_episodes(self.h, max_episodes)
         return lib().orc_sequential_run(self.h, 0)
+
+    def set_start_state(self, states):
+        for k, v in enumerate(states):
+            lib().orc_frirl_set_values_def(self.h, k, float(v))
 
     def episode_eval(self):
         lib().orc_episode_eval(self.h)

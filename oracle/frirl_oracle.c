@@ -984,6 +984,7 @@ double orc_frirl_get_fus(orc_frirl *fr) { return fr->fus_is_rule_inserted; }
 void orc_frirl_set_fus(orc_frirl *fr, double v) { fr->fus_is_rule_inserted = v; }
 void orc_frirl_set_max_episodes(orc_frirl *fr, int n) { fr->max_episodes = n; }
 void orc_frirl_set_max_steps(orc_frirl *fr, int n) { fr->max_steps = n; }
+void orc_frirl_set_values_def(orc_frirl *fr, int k, double v) { fr->statedims[k].values_def = v; }   /* episode start state (frirl_episode.c:46-48) */
 uint64_t orc_frirl_hash(orc_frirl *fr) { return fr->step_hash; }
 long orc_frirl_total_steps(orc_frirl *fr) { return fr->total_steps; }
 unsigned orc_frirl_episode_num(orc_frirl *fr) { return fr->episode_num; }

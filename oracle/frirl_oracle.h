@@ -174,6 +174,7 @@ double orc_frirl_get_fus(orc_frirl *fr);
 void orc_frirl_set_fus(orc_frirl *fr, double v);
 void orc_frirl_set_max_episodes(orc_frirl *fr, int n);
 void orc_frirl_set_max_steps(orc_frirl *fr, int n);
+void orc_frirl_set_values_def(orc_frirl *fr, int k, double v);
 uint64_t orc_frirl_hash(orc_frirl *fr);
 long orc_frirl_total_steps(orc_frirl *fr);
 unsigned orc_frirl_episode_num(orc_frirl *fr);

@@ -150,3 +150,45 @@ def test_demo_rulebases(env, episodes):
         if (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
             assert best[e] == bo
     assert hits > 0
+
+
+@pytest.mark.parametrize("env,episodes", [("mountaincar", 20), ("cartpole", 30), ("acrobot", 40)])
+def test_shared_rule_base_evaluation(env, episodes):
+    """many observations against ONE trained rule base (lane = observation, sequential sums in the
+    reference's order).  Hits / first-max actions exact; Q within tolerance of the oracle AND of the per-environment
+    kernels run on copies of the same base."""
+    import torch
+    Qn = 1000
+    b, fr = demo_device_batch(env, episodes, 1)
+    f = fr.five
+    nant = f.nant
+    prob = b.to_device()
+    rng = np.random.default_rng(9)
+    x = np.zeros((Qn, nant))
+    for i in range(Qn):
+        for k in range(nant):
+            vals = fr.dim(k)["values"]
+            x[i, k] = vals[rng.integers(len(vals))] if (i % 2 == 0 or k == nant - 1) else rng.uniform(vals[0], vals[-1])
+        if i % 5 == 0:
+            x[i] = b.rant[rng.integers(len(b.rant))]
+    conc, hit = prob.vag_concl_shared(dev(x))
+    ave = np.array(fr.action_vevalues)
+    actconc, best = prob.get_best_action_shared(dev(np.ascontiguousarray(x[:, : nant - 1])), dev(ave))
+    torch.cuda.synchronize()
+    conc, hit, actconc, best = conc.cpu().numpy(), hit.cpu().numpy(), actconc.cpu().numpy(), best.cpu().numpy()
+    hits = 0
+    for i in range(0, Qn, 3):
+        h, c = f.vag_concl(x[i])
+        assert hit[i] == h
+        if h >= 0:
+            hits += 1
+            assert conc[i] == c
+        else:
+            assert rel(conc[i], c) <= 1e-12, (i, conc[i], c)      # same summation order as the reference: tighter than the tree
+        bo = fr.get_best_action(x[i, : nant - 1])
+        ac = np.array(fr.actconc)
+        assert rel(actconc[i], ac).max() <= 1e-12
+        srt = np.sort(ac)
+        if (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
+            assert best[i] == bo
+    assert hits > 10
