@@ -218,3 +218,15 @@ extern "C" int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32
     BCHK(hipMemcpy(rconc, b->d_rb + ((size_t)e * (n + 1) + n) * M, sizeof(double) * r, hipMemcpyDeviceToHost), "rconc download");
     return FRIRL_HIP_OK;
 }
+
+extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strategy, double reward_tolerance, int depth, frirl_hip_reduce_result *result)
+{
+    if (!b || !result || e < 0 || e >= b->E) { set_error("frirl_hip_batch_reduce: bad arguments"); return FRIRL_HIP_EINVAL; }
+    const size_t n = b->nant, M = b->maxR;
+    frirl_hip_rulebases one = b->rb;                                 // agent e's slab as a rule-base batch of one
+    one.E = 1;
+    one.rb = b->d_rb + (size_t)e * (n + 1) * M;
+    one.nrules = b->d_nrules + e;
+    if (one.uidx) one.uidx = b->rb.uidx + (size_t)e * n * M;
+    return frirl_hip_reduce_shared(&b->t, &one, &b->agent, b->d_rant + (size_t)e * n * M, strategy, reward_tolerance, depth, nullptr, result, b->s);
+}

@@ -9,6 +9,7 @@
 #include "sweeps.h"
 #include "envs.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <numeric>
@@ -35,20 +36,25 @@ struct SharedTile {
 //        five_remove_rule.c:29-85).
 template <int NANT, int AMAX, bool GBA, bool EXCL>
 __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double *__restrict__ rb, const uint8_t *__restrict__ slot_g, int R,
-                                             int maxR, int p, int A, const double *q, bool live, uint32_t mask, double *conc, unsigned &hit0,
-                                             int &bi, double &bvout)
+                                             int maxR, int p, int abeg, int aend, int nchunks, const double *q, bool live, uint32_t mask,
+                                             double *conc, unsigned &hit0, int &bi, double &bvout)
 {
     constexpr int NS = NANT - 1;
     constexpr int ND = GBA ? NS : NANT;
     const double *qcol = rb + (size_t)NANT * maxR;
-    const int nact = GBA ? A : 1;
-    double bv = 0.0;
-    bi = 0;
+    const int nact = GBA ? aend : 1;
+    // running first maximum over this lane's actions [abeg, aend): `bv < c` as max.inl:21; action 0 always seeds it (so a
+    // NaN there sticks, as in the reference), a lane that starts later seeds with -inf and skips NaNs
+    double bv = -__builtin_inf();
+    bi = abeg;
     hit0 = FRIRL_HIP_NO_HIT;
     // actions in chunks of AMAX accumulators (A = 21: three passes over the L2-resident rule base keep the kernel at
     // ~90 VGPRs instead of 254)
-    for (int a0 = 0; a0 < nact; a0 += AMAX) {
-        const int nacc = (nact - a0 < AMAX) ? nact - a0 : AMAX;
+    // `nchunks` is uniform over the workgroup (the tile staging below has barriers); a lane with fewer actions idles
+    for (int c = 0; c < nchunks; c++) {
+        const int a0 = (GBA ? abeg : 0) + c * AMAX;
+        const int left = nact - a0;
+        const int nacc = left < 0 ? 0 : (left < AMAX ? left : AMAX);
         double sv[AMAX], sw[AMAX];
         unsigned sh[AMAX];
 #pragma unroll
@@ -62,7 +68,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
             }
             if (EXCL) for (int r = threadIdx.x; r < SH_TILE; r += SH_BLOCK) tl.slot[r] = (r < n) ? slot_g[r0 + r] : (uint8_t)255;
             __syncthreads();
-            if (live) {
+            if (live && nacc > 0) {
                 for (int r = 0; r < n; r++) {
                     if (EXCL) { const unsigned sl = tl.slot[r]; if (sl < 32u && ((mask >> sl) & 1u)) continue; }
                     double d0 = q[0] - tl.col[r];
@@ -98,7 +104,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                     if (a0 + a == 0 || bv < c) { bv = c; bi = a0 + a; }
                 }
             }
-            if (a0 == 0) hit0 = sh[0];
+            if (c == 0) hit0 = sh[0];
         }
     }
     bvout = bv;
@@ -121,27 +127,55 @@ __global__ __launch_bounds__(SH_BLOCK) void shared_q_kernel(const double *__rest
     unsigned h0;
     int bi;
     double bv;
-    shared_sweep<NANT, AMAX, GBA, false>(tl, rb, nullptr, nrules[0], maxR, p, A, q, live, 0u, live ? conc + (size_t)qi * (GBA ? A : 1) : nullptr, h0, bi, bv);
+    shared_sweep<NANT, AMAX, GBA, false>(tl, rb, nullptr, nrules[0], maxR, p, 0, A, GBA ? (A + AMAX - 1) / AMAX : 1, q, live, 0u,
+                                         live ? conc + (size_t)qi * (GBA ? A : 1) : nullptr, h0, bi, bv);
     if (!live) return;
     if (GBA) best[qi] = bi;
     else hit[qi] = h0;
 }
 
+// First maximum over the G lanes that share one environment (consecutive lanes of one wave, each holding the first
+// maximum of its own block of actions): combined in block order with the reference's `bv < c` (max.inl:21).
+template <int G>
+__device__ __forceinline__ void group_first_max(double &bv, int &bi)
+{
+    if (G == 1) return;
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1);
+    const int base = lane - (lane % G);
+    double cb = __shfl(bv, base);
+    int ci = __shfl(bi, base);
+#pragma unroll
+    for (int g = 1; g < G; g++) {
+        const double v = __shfl(bv, base + g);
+        const int i = __shfl(bi, base + g);
+        if (cb < v) { cb = v; ci = i; }
+    }
+    bv = cb;
+    bi = ci;
+}
+
 // frirl_test_run's episode (src/frirl/frirl_test_run.c:66-70: construct_rb = 0, reduction_state = 1, frirl_episode) for
-// Q environments sharing one rule base: lane = environment, the whole roll-out in one launch.  No SARSA update
-// (frirl_episode.c:155), so the rule base stays read-only and can be shared.
-template <int NANT, int AMAX, bool EXCL>
+// Q environments sharing one rule base, the whole roll-out in one launch.  No SARSA update (frirl_episode.c:155), so the
+// rule base stays read-only and can be shared.  G consecutive lanes serve one environment, each evaluating its own
+// block of actions (G = 1 for throughput when Q fills the chip; G = 4 / 8 cut the per-step latency when Q is small, the
+// case of the reduction's replays); the environment state is kept redundantly by all G lanes.
+template <int NANT, int AMAX, int G, bool EXCL>
 __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                                    const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
                                                                    const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro)
 {
-    constexpr int NS = NANT - 1;
+    constexpr int NS = NANT - 1, EPB = SH_BLOCK / G;
     __shared__ SharedTile<NANT> tl;
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
-    const int qi = blockIdx.x * SH_BLOCK + threadIdx.x;
+    const int sub = threadIdx.x % G;
+    const int qi = blockIdx.x * EPB + threadIdx.x / G;
     const bool exists = qi < Q;
     const int R = nrules[0];
     const int p = ag.p > 0 ? ag.p : NANT;
+    const int apl = (ag.A + G - 1) / G;                              // actions per lane
+    const int abeg = (sub * apl < ag.A) ? sub * apl : ag.A;
+    const int aend = (abeg + apl < ag.A) ? abeg + apl : ag.A;
+    const int nchunks = (apl + AMAX - 1) / AMAX;
     for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += SH_BLOCK) grid_s[i] = ag.grid_values[i];
     if ((int)threadIdx.x < ag.A) tl.ave[threadIdx.x] = ag.action_ve[threadIdx.x];
     const uint32_t mask = (EXCL && exists && ro.exclude_mask) ? ro.exclude_mask[qi] : 0u;
@@ -154,7 +188,8 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
     unsigned h0;
     int a;
     double bv;
-    shared_sweep<NANT, AMAX, true, EXCL>(tl, rb, ro.rule_slot, R, maxR, p, ag.A, q, exists, mask, nullptr, h0, a, bv);   // :78 (un-quantised start state)
+    shared_sweep<NANT, AMAX, true, EXCL>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, exists, mask, nullptr, h0, a, bv);   // :78 (un-quantised start state)
+    group_first_max<G>(bv, a);
     a = e_greedy(ag, a, (uint32_t)qi, 0u, 0u);
     double action = grid_s[NS * FRIRL_HIP_MAX_GRID + a];                                                 // :82
     int steps = 0, success = 0;
@@ -172,7 +207,8 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
             for (int k = 0; k < NS; k++) q[k] = observe_ve(u, ve, U, k, qs[k]);
         }
         int pa;
-        shared_sweep<NANT, AMAX, true, EXCL>(tl, rb, ro.rule_slot, R, maxR, p, ag.A, q, active, mask, nullptr, h0, pa, bv);   // :148
+        shared_sweep<NANT, AMAX, true, EXCL>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, active, mask, nullptr, h0, pa, bv);   // :148
+        group_first_max<G>(bv, pa);
         if (active) {
             pa = e_greedy(ag, pa, (uint32_t)qi, 0u, (uint32_t)step);
             action = grid_s[NS * FRIRL_HIP_MAX_GRID + pa];                                               // :151
@@ -182,7 +218,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
             if (success == 1) active = false;                                                            // :183
         }
     }
-    if (!exists) return;
+    if (!exists || sub != 0) return;
     ro.steps[qi] = steps;
     ro.reward[qi] = total;
     if (ro.success) ro.success[qi] = success;
@@ -243,15 +279,35 @@ extern "C" int frirl_hip_get_best_action_shared(const frirl_hip_tables *t, const
     return check_launch("frirl_hip_get_best_action_shared");
 }
 
-template <int N, int AMAX>
+template <int N, int AMAX, int G>
 static void launch_rollout(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
                            hipStream_t s)
 {
-    const dim3 grid((Q + frirl::SH_BLOCK - 1) / frirl::SH_BLOCK);
+    constexpr int EPB = frirl::SH_BLOCK / G;
+    const dim3 grid((Q + EPB - 1) / EPB);
     if (ro->exclude_mask && ro->rule_slot)
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, true>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, true>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
     else
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, false>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, false>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+}
+
+// lanes per environment: 1 once the environments alone fill the chip, else split the actions over 4 (A <= 4) or 8 lanes
+static int rollout_group(int Q, int A)
+{
+    if (const char *e = getenv("FRIRL_HIP_ROLLOUT_GROUP")) { const int g = atoi(e); if (g == 1 || (g == 4 && A <= 4) || (g == 8 && A > 4)) return g; }
+    if (A < 2 || Q >= 131072) return 1;
+    return A <= 4 ? 4 : 8;
+}
+
+template <int N>
+static void launch_rollout_n(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                             hipStream_t s)
+{
+    const int G = rollout_group(Q, ag->A);
+    if (G == 4) launch_rollout<N, 1, 4>(t, b, ag, Q, ro, s);
+    else if (G == 8) launch_rollout<N, 4, 8>(t, b, ag, Q, ro, s);
+    else if (ag->A <= 4) launch_rollout<N, 4, 1>(t, b, ag, Q, ro, s);
+    else launch_rollout<N, 8, 1>(t, b, ag, Q, ro, s);
 }
 
 extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, int32_t Q,
@@ -267,8 +323,8 @@ extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_h
         return FRIRL_HIP_EINVAL;
     }
     hipStream_t s = as_stream(stream);
-    if (t->nant == 3) { if (agent->A <= 4) launch_rollout<3, 4>(t, b, agent, Q, ro, s); else launch_rollout<3, 8>(t, b, agent, Q, ro, s); }
-    else { if (agent->A <= 4) launch_rollout<5, 4>(t, b, agent, Q, ro, s); else launch_rollout<5, 8>(t, b, agent, Q, ro, s); }
+    if (t->nant == 3) launch_rollout_n<3>(t, b, agent, Q, ro, s);
+    else launch_rollout_n<5>(t, b, agent, Q, ro, s);
     return check_launch("frirl_hip_rollout_shared");
 }
 

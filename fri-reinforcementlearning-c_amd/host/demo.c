@@ -34,7 +34,8 @@ int main(int argc, char **argv)
     frirl_parse_cmdline(&fr, fargc, fargv);
     if (agents > 0) {
         snprintf(name, sizeof name, "%s.batch.frirlrb.txt", env);
-        return frirl_demo_batch_run(env, agents, max_episodes > 0 ? max_episodes : fr.max_episodes, name, 1) == agents ? 0 : 3;
+        if (reduce == 1 || reduce == 2) snprintf(name, sizeof name, "%s.batch.reduced%d.frirlrb.txt", env, reduce);
+        return frirl_demo_batch_run_reduce(env, agents, max_episodes > 0 ? max_episodes : fr.max_episodes, reduce, name, 1) == agents ? 0 : 3;
     }
     if (frirl_demo_setup(&fr, env) != 0) return 2;
     if (max_episodes > 0) fr.max_episodes = max_episodes;

@@ -245,6 +245,11 @@ int frirl_demo_describe(const char *env, int *nstates, int *U, int *A, double *u
  * trig (include/frirl_hip.h), so the learned rule bases equal the host demo's up to the trig's last-bit differences. */
 int frirl_demo_batch_run(const char *env, int agents, int max_episodes, const char *out_txt, int verbose)
 {
+    return frirl_demo_batch_run_reduce(env, agents, max_episodes, 0, out_txt, verbose);
+}
+
+int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, int reduce_strategy, const char *out_txt, int verbose)
+{
     int ns, U, A, max_steps, nant, k, j, R0, episodes = 0, rc;
     double *u, *ve, *grid, *action_ve, *rant0, *rconc0;
     int grid_len[FRIRL_HIP_MAX_NANT];
@@ -284,6 +289,14 @@ int frirl_demo_batch_run(const char *env, int agents, int max_episodes, const ch
         printf("batch %s: agents %lld episodes %d converged %lld env-steps %lld mean-rules %.3f mean-reward %.6f (min %.6f max %.6f)\n", env,
                (long long)st.agents, episodes, (long long)st.converged, (long long)st.total_env_steps, st.rules_sum / st.agents,
                st.reward_sum / st.agents, st.reward_min, st.reward_max);
+    if (reduce_strategy == 1 || reduce_strategy == 2) {
+        frirl_hip_reduce_result rr;
+        rc = frirl_hip_batch_reduce(b, 0, reduce_strategy, 0.0, 0, &rr);
+        if (rc) five_dropin_fatal("frirl_demo_batch_run(reduce)", rc);
+        if (verbose)
+            printf("batch %s: agent 0 reduced %d -> %d rules (strategy %d, %d launches, %d replays, episode of %d steps, reward %.6f)\n", env,
+                   rr.rules_before, rr.rules_after, reduce_strategy, rr.rounds, rr.rollouts, rr.steps_incremental, rr.reward);
+    }
     if (out_txt) {
         int32_t R = 0;
         double *rant = malloc(sizeof(double) * 1024 * nant), *rconc = malloc(sizeof(double) * 1024);

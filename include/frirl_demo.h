@@ -19,5 +19,8 @@ int frirl_demo_describe(const char *env, int *nstates, int *U, int *A, double *u
  * when out_txt != NULL the rule base of agent 0 is written there in the reference's text format.
  * Returns the number of converged agents, or -1 on error. */
 int frirl_demo_batch_run(const char *env, int agents, int max_episodes, const char *out_txt, int verbose);
+/* the same, followed by the rule-base reduction (strategy 1 | 2, frirl_sequential_run.c:170-350) of agent 0's rule base on the
+ * GPU (frirl_hip_batch_reduce); out_txt then holds the REDUCED rule base.  reduce_strategy 0 = frirl_demo_batch_run. */
+int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, int reduce_strategy, const char *out_txt, int verbose);
 
 #endif

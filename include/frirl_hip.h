@@ -389,6 +389,9 @@ int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *epi
 int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out);
 /* rule base of agent e: *R rules, rant HOST [>= *R][nant] (AoS), rconc HOST [>= *R] (pass NULL to query *R only) */
 int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32_t *R, double *rant, double *rconc);
+/* frirl_sequential_run's reduction phase (frirl_sequential_run.c:170-350) for agent e's rule base, in place, through
+ * frirl_hip_reduce_shared (speculative batched try-remove); the other agents are untouched */
+int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strategy, double reward_tolerance, int depth, frirl_hip_reduce_result *result);
 
 #ifdef __cplusplus
 }

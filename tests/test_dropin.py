@@ -170,3 +170,26 @@ def test_c_level_batched_agents(env, rules, built, tmp_path):
     assert rel.max() <= 1e-6
     steps = {"mountaincar": 15548, "acrobot": 21207, "cartpole": 33002}[env]
     assert f"env-steps {96 * steps}" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,strategy", [("mountaincar", 1), ("mountaincar", 2), ("acrobot", 1)])
+def test_c_level_batched_reduction(env, strategy, built, tmp_path):
+    """`frirl_demo --agents N --reduce S`: learn on the GPU, then reduce agent 0's rule base with the speculative batched
+    try-remove (frirl_hip_batch_reduce -> frirl_hip_reduce_shared), all from C.  The surviving rules are the ones the
+    oracle's sequential reduction keeps (portable trig), in the same order."""
+    from oracle import binding as ob
+    lib, demo = built
+    r = subprocess.run([demo, "--env", env, "--agents", "8", "--reduce", str(strategy)], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    mine = load_rb(tmp_path / f"{env}.batch.reduced{strategy}.frirlrb.txt")
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1
+    R0 = fr.five.R
+    fr.reduce(strategy, 0.0)
+    f = fr.five
+    assert f"agent 0 reduced {R0} -> {f.R} rules" in r.stdout, r.stdout[-600:]
+    assert mine.shape == (f.R, f.nant + 1)
+    assert (mine[:, :-1] == np.array(f.rant[: f.R])).all()
+    rel = np.abs(mine[:, -1] - f.rconc[: f.R]) / np.maximum(np.abs(f.rconc[: f.R]), 1e-9)
+    assert rel.max() <= 1e-6
