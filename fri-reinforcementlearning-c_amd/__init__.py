@@ -91,6 +91,9 @@ SIGNATURES = {
     "frirl_hip_rollout_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_int32, C.POINTER(RolloutDesc), C.c_void_p]),
     "frirl_hip_reduce_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_void_p, C.c_int, C.c_double, C.c_int,
                                           C.POINTER(C.c_int32), C.POINTER(ReduceResult), C.c_void_p]),
+    "frirl_hip_lanes_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "frirl_hip_episode_run_lanes": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_int32,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     "five_hip_add_rule": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "frirl_hip_update_sarsa": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p,
@@ -429,6 +432,20 @@ def episode_run(problem, agent, envs, nsteps, lds_rules, stream=None):
                                       _stream(stream)), "frirl_hip_episode_run")
 
 
+def episode_run_lanes(problem, agent, envs, nsteps, workspace=None, stream=None):
+    """frirl_hip_episode_run_lanes: lane-group episodes for many agents with small rule bases; `workspace` is a
+    float64 CUDA tensor of >= lanes_workspace_elems(problem, agent) elements (allocated and cached on the problem if None)."""
+    import torch
+    need = lib().frirl_hip_lanes_workspace_bytes(problem.nant, problem.E, problem.maxR, agent.A)
+    if workspace is None:
+        workspace = getattr(problem, "_lanes_ws", None)
+        if workspace is None or workspace.numel() * 8 < need:
+            workspace = torch.empty((need // 8,), dtype=torch.float64, device=problem.rb.device)
+            problem._lanes_ws = workspace
+    check(lib().frirl_hip_episode_run_lanes(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), nsteps,
+                                            _ptr(workspace), workspace.numel() * 8, _stream(stream)), "frirl_hip_episode_run_lanes")
+
+
 def can_run_persistent(problem, agent):
     return agent.A <= 8 and 2 * 8 * problem.nant * problem.U <= 16 * 1024
 
@@ -454,7 +471,7 @@ class Convergence:
                                                  _stream(stream)), "frirl_hip_convergence_update")
 
 
-def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None, persistent=True, persistent_max_rules=256):
+def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None, persistent=True, persistent_max_rules=256, lanes=False):
     """Batched construct run: frirl_sequential_run's loop (reference frirl_sequential_run.c:55-165) for E agents
     at once.  Episodes run until every environment's rule base is "considered complete" or max_episodes-1 episodes
     have run (:51,59).  Converged environments are masked out of later episodes.  Returns the Convergence object."""
@@ -465,7 +482,11 @@ def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=No
         episode_begin(problem, agent, envs)
         envs.done.copy_(torch.maximum(envs.done, conv.converged))       # converged agents sit this episode out
         steps = 0
-        if persistent and can_run_persistent(problem, agent):
+        if lanes:
+            # many agents, small rule bases: lane-group kernel, the whole episode in one launch (no reductions / barriers)
+            episode_run_lanes(problem, agent, envs, max_steps)
+            steps = max_steps
+        elif persistent and can_run_persistent(problem, agent):
             # small rule bases: the whole episode in one launch out of LDS; an environment whose rule base outgrows
             # the LDS slab comes back not-done (status FULL) and finishes through the step kernel below
             # (measured: it pays only while the LDS slab is small enough for >= ~12 waves per CU, i.e. the 256-rule slab;

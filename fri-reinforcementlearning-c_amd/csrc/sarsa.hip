@@ -636,6 +636,12 @@ static int check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b
     return check_device();
 }
 
+// shared with lanes.hip
+int frirl_check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs, const char *who)
+{
+    return check_episode(t, b, agent, envs, who);
+}
+
 extern "C" int frirl_hip_episode_begin(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                                        const frirl_hip_envs *envs, void *stream)
 {

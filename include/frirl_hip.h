@@ -283,6 +283,18 @@ int frirl_hip_episode_step(const frirl_hip_tables *t, const frirl_hip_rulebases 
 int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                             const frirl_hip_envs *envs, int32_t nsteps, void *stream);
 
+/* Lane-group form for MANY agents with SMALL rule bases (the demos' learning regime; the reference's frirl_omp_run model
+ * of one agent per core, frirl_agent.c:294-325, at GPU width): G = 4 or 8 consecutive lanes own one environment, each
+ * lane evaluates its share of the A + 1 conclusions of a step over ALL rules sequentially -- the reference's summation
+ * order -- so a step needs no reduction and no barrier; up to nsteps consecutive steps per launch (same contract as
+ * frirl_hip_episode_steps: finished environments sit out, status[e] = last update).  The rule bases are transposed into
+ * `workspace` ([dev], >= frirl_hip_lanes_workspace_bytes) on entry and back on exit.  Decisions (actions, hits,
+ * inserted rules) and distances are those of the step kernel; interpolated Q agrees to ~1e-15 (different summation
+ * order than the tree of the per-environment kernels, same as the reference's). */
+size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
+int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
+                                const frirl_hip_envs *envs, int32_t nsteps, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Persistent form for SMALL rule bases (the demos' learning regime): one wave keeps its environment's rule base,
  * the tables and the episode state in LDS and runs up to nsteps consecutive steps without a global round trip per
  * step; results are bit-identical to nsteps calls of frirl_hip_episode_step.  lds_rules (<= 1024) is the LDS slab

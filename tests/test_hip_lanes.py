@@ -1,0 +1,80 @@
+"""Lane-group learning kernel (frirl_hip_episode_run_lanes: G lanes per environment, sequential per-lane Shepard sums,
+transposed rule bases) against the oracle's whole demo runs and against the per-environment step kernel."""
+import numpy as np
+import pytest
+
+import frirl_amd
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env,episodes,steps,rules", [("mountaincar", 29, 15548, 110), ("cartpole", 58, 33002, 182), ("acrobot", 110, 21207, 367)])
+def test_lane_group_training_reaches_the_oracle_rule_base(env, episodes, steps, rules):
+    """E = 21 agents (ragged last wave) learn from the corner rule base through the lane-group kernel; every agent must
+    end exactly where the oracle ends: episodes, total steps, rule count, antecedents and order bit-exact, Q <= 1e-9."""
+    import torch
+    E = 21
+    dev = torch.device("cuda", 0)
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1 and fr.five.R == rules and fr.total_steps == steps
+    prob, agent, envs = frirl_amd.demo_fresh_batch(env, E, 512, dev)
+    total = torch.zeros((E,), dtype=torch.int64, device=dev)
+
+    def on_episode(ep, conv):
+        total.add_(envs.ep_steps.long() * (conv.episodes == ep).long())
+
+    conv = frirl_amd.train(prob, agent, envs, on_episode=on_episode, lanes=True)
+    torch.cuda.synchronize()
+    assert (conv.converged == 1).all()
+    assert (conv.episodes == episodes).all(), conv.episodes.tolist()
+    assert (total == steps).all(), total.tolist()
+    assert (prob.nrules == rules).all()
+    f = fr.five
+    rant = envs.rant[:, :, :rules].cpu().numpy()
+    assert (rant == f.rant[:rules].T[None]).all(), "antecedents / rule order"
+    rb = prob.rb.cpu().numpy()
+    assert (rb[:, : f.nant, :rules] == f.veval[None, :, :rules]).all(), "VE columns"
+    q = rb[:, prob.nant, :rules]
+    rel = np.abs(q - f.rconc[None, :rules]) / np.maximum(np.abs(f.rconc[None, :rules]), 1e-9)
+    assert rel.max() <= 1e-9, rel.max()
+    if prob.uidx is not None:
+        ui = prob.uidx[:, :, :rules].cpu().numpy().astype(np.int64) & 0xFFFF
+        assert (ui == f.uidx[None, :, :rules]).all(), "index mirror"
+
+
+@pytest.mark.parametrize("env", ["mountaincar", "acrobot", "cartpole"])
+def test_lane_group_steps_equal_step_kernel(env):
+    """Same start, per-environment start states (different trajectories, ragged episode ends): chunks of lane-group
+    steps vs the same number of frirl_hip_episode_step launches -- states, actions, rule counts, status, step counts
+    identical; Q within 1e-10."""
+    import torch
+    dev = torch.device("cuda", 0)
+    E = 37
+    d = frirl_amd.demo_describe(env)
+    g = torch.Generator(device=dev).manual_seed(2)
+    cols = []
+    for k in range(d["nstates"]):
+        vals = torch.from_numpy(d["grids"][k]).to(dev)
+        cols.append(vals[torch.randint(0, len(vals), (E,), generator=g, device=dev)])
+    start = torch.stack(cols, 1).contiguous()
+    pa, agent, ea = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300)
+    pb, _, eb = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300)
+    for episode in range(3):
+        frirl_amd.episode_begin(pa, agent, ea)
+        frirl_amd.episode_begin(pb, agent, eb)
+        for chunk in (1, 7, 50, 300):
+            frirl_amd.episode_run_lanes(pa, agent, ea, chunk)
+            frirl_amd.episode_steps(pb, agent, eb, chunk)
+            torch.cuda.synchronize()
+            assert (ea.ep_steps == eb.ep_steps).all(), (episode, chunk)
+            assert (ea.done == eb.done).all()
+            assert (pa.nrules == pb.nrules).all(), (episode, chunk, pa.nrules.tolist(), pb.nrules.tolist())
+            assert (ea.states == eb.states).all() and (ea.q_ant == eb.q_ant).all()
+            assert (ea.fus == eb.fus).all() and (ea.ep_reward == eb.ep_reward).all()
+            R = int(pa.nrules.max())
+            qa, qb = pa.rb[:, pa.nant, :R], pb.rb[:, pb.nant, :R]
+            assert ((qa - qb).abs() <= 1e-10 * qb.abs().clamp(min=1.0)).all()
+            assert (pa.rb[:, : pa.nant, :R] == pb.rb[:, : pb.nant, :R]).all()
+            assert (ea.rant[:, :, :R] == eb.rant[:, :, :R]).all()
+        assert (ea.done == 1).all()

@@ -8,6 +8,7 @@ import torch, frirl_amd
 env = sys.argv[1] if len(sys.argv) > 1 else "mountaincar"
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 diversify = len(sys.argv) > 3 and sys.argv[3] == "div"
+lanes = os.environ.get("LANES", "0") == "1"      # lane-group kernel (frirl_hip_episode_run_lanes)
 dev = torch.device("cuda", 0)
 d = frirl_amd.demo_describe(env)
 start = None
@@ -23,8 +24,8 @@ total = torch.zeros((), dtype=torch.int64, device=dev)
 def on_ep(ep, conv):
     total.add_((envs.ep_steps.long() * (conv.episodes == ep).long()).sum())
 torch.cuda.synchronize(); t0 = time.perf_counter()
-conv = frirl_amd.train(prob, agent, envs, on_episode=on_ep, max_episodes=400)
+conv = frirl_amd.train(prob, agent, envs, on_episode=on_ep, max_episodes=400, lanes=lanes)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(json.dumps({"env": env, "agents": E, "diversified_start": diversify, "wall_s": dt, "env_steps": int(total), "env_steps_per_s": int(total) / dt,
+print(json.dumps({"lanes": lanes, "env": env, "agents": E, "diversified_start": diversify, "wall_s": dt, "env_steps": int(total), "env_steps_per_s": int(total) / dt,
                   "converged": int(conv.converged.sum()), "episodes_max": int(conv.episodes.max()), "rules_min": int(prob.nrules.min()),
                   "rules_max": int(prob.nrules.max())}))
