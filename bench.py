@@ -234,8 +234,11 @@ def main():
         learn_leg = {"value": tot[0].item() / ldt, "unit": "env-steps/s", "agents": lE * world, "wall_s": ldt, "env_steps": tot[0].item(),
                      "agents_converged": tot[1].item(), "episodes_to_converge": int(conv.episodes.max().item()),
                      "mean_final_rules": tot[2].item() / (lE * world),
+                     "kernel": "episode_run_lanes (lane groups)" if frirl_amd.lib().frirl_hip_lanes_preferred(lprob.nant, lE, lagent.A)
+                               else "episode_run / episode_step (one wave per environment)",
                      "note": "whole construct run from the 2^nant corner rules (reference: 15548 / 33002 / 21207 steps per agent for "
-                             "mountaincar / cartpole / acrobot); rule bases stay small (<= 367 rules), so this leg is launch/latency bound"}
+                             "mountaincar / cartpole / acrobot); rule bases stay small (<= 367 rules): latency / occupancy bound at "
+                             "8192 agents, 1.2-1.5e9 env-steps/s at 65536 mountaincar agents (tools/learn_bench.py)"}
 
     if rank == 0:
         evals = float(E) * R * args.steps * world

@@ -91,6 +91,7 @@ SIGNATURES = {
     "frirl_hip_rollout_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_int32, C.POINTER(RolloutDesc), C.c_void_p]),
     "frirl_hip_reduce_shared": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_void_p, C.c_int, C.c_double, C.c_int,
                                           C.POINTER(C.c_int32), C.POINTER(ReduceResult), C.c_void_p]),
+    "frirl_hip_lanes_preferred": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "frirl_hip_lanes_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frirl_hip_episode_run_lanes": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_int32,
                                               C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -471,13 +472,15 @@ class Convergence:
                                                  _stream(stream)), "frirl_hip_convergence_update")
 
 
-def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None, persistent=True, persistent_max_rules=256, lanes=False):
+def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=None, persistent=True, persistent_max_rules=256, lanes=None):
     """Batched construct run: frirl_sequential_run's loop (reference frirl_sequential_run.c:55-165) for E agents
     at once.  Episodes run until every environment's rule base is "considered complete" or max_episodes-1 episodes
     have run (:51,59).  Converged environments are masked out of later episodes.  Returns the Convergence object."""
     import torch
     conv = Convergence(problem, problem.rb.device)
     max_steps = agent.desc.max_steps
+    if lanes is None:           # lane-group kernel where it is the faster form (many agents / small rule bases)
+        lanes = bool(lib().frirl_hip_lanes_preferred(problem.nant, problem.E, agent.A))
     for ep in range(1, max_episodes):
         episode_begin(problem, agent, envs)
         envs.done.copy_(torch.maximum(envs.done, conv.converged))       # converged agents sit this episode out

@@ -13,6 +13,9 @@ struct frirl_hip_batch {
     int32_t nant, U, E, maxR;
     hipStream_t s;
     double *d_u, *d_ve, *d_rb, *d_rant, *d_grid, *d_ave, *d_states, *d_q_ant, *d_ep_reward, *d_start, *d_prev_reward, *d_prev_rconc, *d_tmp;
+    uint16_t *d_uidx;            // 16-bit universe-index mirror of the antecedents (compressed scans, lane-group index store)
+    void *d_lanes_ws;            // transposed rule bases of the lane-group kernel (allocated on first use)
+    size_t lanes_ws_bytes;
     int32_t *d_nrules, *d_fus, *d_done, *d_ep_steps, *d_status, *d_episode, *d_prev_nrules, *d_prev_steps, *d_converged, *d_episodes;
     frirl_hip_tables t;
     frirl_hip_rulebases rb;
@@ -63,7 +66,7 @@ extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
     if (b->s) (void)hipStreamSynchronize(b->s);
     void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
                     b->d_prev_rconc, b->d_tmp, b->d_nrules, b->d_fus, b->d_done, b->d_ep_steps, b->d_status, b->d_episode, b->d_prev_nrules,
-                    b->d_prev_steps, b->d_converged, b->d_episodes};
+                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_uidx, b->d_lanes_ws};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->s) (void)hipStreamDestroy(b->s);
     delete b;
@@ -84,6 +87,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
     ok = ok && dalloc(&b->d_prev_rconc, E * M) && dalloc(&b->d_tmp, E * (n + 1)) && dalloc(&b->d_nrules, E) && dalloc(&b->d_fus, E) && dalloc(&b->d_done, E);
     ok = ok && dalloc(&b->d_ep_steps, E) && dalloc(&b->d_status, E) && dalloc(&b->d_episode, E) && dalloc(&b->d_prev_nrules, E) && dalloc(&b->d_prev_steps, E);
     ok = ok && dalloc(&b->d_converged, E) && dalloc(&b->d_episodes, E + 1);
+    if (ok && d->U <= 65536) ok = dalloc(&b->d_uidx, E * n * M);
     if (ok && d->start_states) ok = dalloc(&b->d_start, E * ns) && hipMemcpy(b->d_start, d->start_states, sizeof(double) * E * ns, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(b->d_u, d->u, sizeof(double) * n * d->U, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(b->d_ve, d->ve, sizeof(double) * n * d->U, hipMemcpyHostToDevice) == hipSuccess;
@@ -91,7 +95,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
     ok = ok && hipMemcpy(b->d_ave, d->agent.action_ve, sizeof(double) * d->agent.A, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { set_error("frirl_hip_batch_create: HIP allocation/copy failed: %s", hipGetErrorString(hipGetLastError())); frirl_hip_batch_destroy(b); return nullptr; }
     b->t.nant = b->nant; b->t.U = b->U; b->t.u = b->d_u; b->t.ve = b->d_ve;
-    b->rb.E = b->E; b->rb.maxR = b->maxR; b->rb.rb = b->d_rb; b->rb.nrules = b->d_nrules; b->rb.uidx = nullptr;
+    b->rb.E = b->E; b->rb.maxR = b->maxR; b->rb.rb = b->d_rb; b->rb.nrules = b->d_nrules; b->rb.uidx = b->d_uidx;
     b->agent = d->agent;
     b->agent.grid_values = b->d_grid;
     b->agent.action_ve = b->d_ave;
@@ -127,6 +131,15 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
     hipLaunchKernelGGL(frirl::mask_converged_kernel, dim3((b->E + 255) / 256), dim3(256), 0, b->s, b->d_done, b->d_converged, b->E);
     const int chunk = 64;
     int32_t running = 1;
+    // many agents / small rule bases: lane-group kernel, the whole episode in one launch (frirl_hip_episode_run_lanes)
+    if (frirl_hip_lanes_preferred(b->nant, b->E, b->agent.A)) {
+        if (!b->d_lanes_ws) {
+            b->lanes_ws_bytes = frirl_hip_lanes_workspace_bytes(b->nant, b->E, b->maxR, b->agent.A);
+            BCHK(hipMalloc(&b->d_lanes_ws, b->lanes_ws_bytes), "lane-group workspace");
+        }
+        if ((rc = frirl_hip_episode_run_lanes(&b->t, &b->rb, &b->agent, &b->envs, b->agent.max_steps, b->d_lanes_ws, b->lanes_ws_bytes, b->s))) return rc;
+        running = 0;
+    } else
     // small rule bases: whole episode in one launch out of LDS (frirl_hip_episode_run); environments that outgrow the
     // LDS slab come back not-done and finish through the step kernel below
     if (b->agent.A <= 8 && 2 * sizeof(double) * b->nant * (size_t)b->U <= 16 * 1024) {

@@ -8,17 +8,25 @@
 // rules in index order, accumulating its Shepard sums sequentially (the reference's own summation order,
 // FIVEVagConcl.c:224-235).  The only cross-lane traffic is a handful of __shfl's per step inside the group.
 //
-// Layout: the rule bases are transposed into `T[tile][k][r][i]` (tile = wave, k = column 0..nant, r = rule, i =
-// environment within the tile), so that at a given rule the 64/G environments of a wave read one contiguous run; the
-// G lanes of a group read the same address.  frirl_hip_episode_run_lanes imports the canonical slabs, runs, and exports
-// them again (two small transposes per call: only the first nrules[e] rules move).
+// Layout: the rule bases are transposed so that at a given rule the 64/G environments of a wave read one contiguous run
+// (the G lanes of a group read the same address); tile = wave, i = environment within the tile:
+//   f64 store   T[tile][k][r][i]            doubles, k = 0..nant (VE columns + consequents): 8(nant+1) B per rule
+//   index store Ti[tile][r][i] + Tq[tile][r][i]  one packed record of nant 16-bit universe indices (8 or 16 B) + the
+//               consequent; VE values are gathered from an LDS copy of the tables (rb[e][k][r] == ve[k][uidx[e][k][r]]
+//               exactly, five_add_rule.c:76-81): 16 (nant <= 4) or 24 B per rule and 2 loads instead of nant+1
+// frirl_hip_episode_run_lanes imports the canonical slabs, runs, and exports them again (two small transposes per call:
+// only the first nrules[e] rules move).
 #include "sweeps.h"
 #include "envs.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace frirl {
 
-// canonical rb[e][k][r]  ->  T[((tile*(nant+1) + k)*maxR + r)*EPW + i]   (e = tile*EPW + i), rules r < nrules[e]
+constexpr int LN_WPB = 4;                         // waves (tiles) per workgroup: they share the LDS tables
+constexpr int LN_BLOCK = LN_WPB * FRIRL_WAVE;
+
+// ---- import / export: canonical rb[e][k][r] (+ uidx[e][k][r]) <-> tiles, rules r < nrules[e] ---------------------------
 __global__ __launch_bounds__(256) void lanes_import_kernel(const double *__restrict__ rb, const int32_t *__restrict__ nrules, int E, int nant1, int maxR,
                                                             int EPW, double *__restrict__ T)
 {
@@ -40,12 +48,13 @@ __global__ __launch_bounds__(256) void lanes_import_kernel(const double *__restr
     }
 }
 
+// k = 0..nant1-1 selects the column exported from the f64 tiles (kfirst: first column to export)
 __global__ __launch_bounds__(256) void lanes_export_kernel(double *__restrict__ rb, const int32_t *__restrict__ nrules, int E, int nant1, int maxR, int EPW,
-                                                            const double *__restrict__ T)
+                                                            const double *__restrict__ T, int tile_cols, int kfirst)
 {
     __shared__ double s[16][65];
     __shared__ int nr[16];
-    const int tile = blockIdx.x, k = blockIdx.y, e0 = tile * EPW;
+    const int tile = blockIdx.x, kt = blockIdx.y, k = kfirst + kt, e0 = tile * EPW;
     if ((int)threadIdx.x < EPW) nr[threadIdx.x] = (e0 + (int)threadIdx.x < E) ? nrules[e0 + threadIdx.x] : 0;
     __syncthreads();
     int rmax = 0;
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(256) void lanes_export_kernel(double *__restrict__ 
     for (int r0 = 0; r0 < rmax; r0 += 64) {
         for (int idx = threadIdx.x; idx < EPW * 64; idx += 256) {
             const int j = idx / EPW, i = idx - j * EPW, r = r0 + j;
-            s[i][j] = (r < maxR) ? T[(((size_t)tile * nant1 + k) * maxR + r) * EPW + i] : 0.0;
+            s[i][j] = (r < maxR) ? T[(((size_t)tile * tile_cols + kt) * maxR + r) * EPW + i] : 0.0;
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < EPW * 64; idx += 256) {
@@ -64,40 +73,140 @@ __global__ __launch_bounds__(256) void lanes_export_kernel(double *__restrict__ 
     }
 }
 
-// The per-lane rule loops are chains of dependent global loads (~0.5 us each with one or two waves per SIMD): rules are
-// fetched UR at a time into registers, two batches in flight (the next one is requested before the current one is
-// consumed).  Out-of-range slots re-read the last rule (never consumed).
-constexpr int LN_UR = 4;
+// index store: packed records (W 32-bit words, two 16-bit indices each) + consequents
+__global__ __launch_bounds__(256) void lanes_import_idx_kernel(const double *__restrict__ rb, const uint16_t *__restrict__ uidx,
+                                                                const int32_t *__restrict__ nrules, int E, int nant, int maxR, int EPW, int W,
+                                                                uint32_t *__restrict__ Ti, double *__restrict__ Tq)
+{
+    __shared__ uint32_t sw[16][65][4];
+    __shared__ double sq[16][65];
+    const int tile = blockIdx.x, e0 = tile * EPW;
+    int rmax = 0;
+    for (int i = 0; i < EPW; i++) if (e0 + i < E) { const int r = nrules[e0 + i]; rmax = r > rmax ? r : rmax; }
+    for (int r0 = 0; r0 < rmax; r0 += 64) {
+        for (int idx = threadIdx.x; idx < EPW * 64; idx += 256) {
+            const int i = idx >> 6, j = idx & 63, e = e0 + i, r = r0 + j;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            double q = 0.0;
+            if (e < E && r < maxR) {
+                for (int k = 0; k < nant; k++) w[k >> 1] |= (uint32_t)uidx[((size_t)e * nant + k) * maxR + r] << (16 * (k & 1));
+                q = rb[((size_t)e * (nant + 1) + nant) * maxR + r];
+            }
+            for (int x = 0; x < 4; x++) sw[i][j][x] = w[x];
+            sq[i][j] = q;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < EPW * 64; idx += 256) {
+            const int j = idx / EPW, i = idx - j * EPW, r = r0 + j;
+            if (r < maxR) {
+                const size_t o = ((size_t)tile * maxR + r) * EPW + i;
+                for (int x = 0; x < W; x++) Ti[o * W + x] = sw[i][j][x];
+                Tq[o] = sq[i][j];
+            }
+        }
+        __syncthreads();
+    }
+}
 
-template <int NCOL>
-struct RuleBatch {
-    double c[LN_UR][NCOL];
-    __device__ __forceinline__ void load(const double *__restrict__ Te, int maxR, int EPW, int r0, int stride, int R)
+// ---- rule stores ------------------------------------------------------------------------------------------------
+template <int NANT>
+struct StoreF64 {
+    static constexpr int UR = 4;
+    double *Te;                                  // tile base + environment slot
+    int maxR, EPW;
+    struct Rec { double c[NANT + 1]; };
+    template <bool NEEDQ>
+    __device__ __forceinline__ Rec load(int r) const
+    {
+        Rec x;
+#pragma unroll
+        for (int k = 0; k < NANT; k++) x.c[k] = Te[(unsigned)((k * maxR + r) * EPW)];
+        x.c[NANT] = NEEDQ ? Te[(unsigned)((NANT * maxR + r) * EPW)] : 0.0;
+        return x;
+    }
+    __device__ __forceinline__ void decode(const Rec &x, double (&c)[NANT + 1]) const
     {
 #pragma unroll
-        for (int j = 0; j < LN_UR; j++) {
-            int r = r0 + j * stride;
-            r = r < R ? r : R - 1;
-            r = r < 0 ? 0 : r;
+        for (int k = 0; k <= NANT; k++) c[k] = x.c[k];
+    }
+    __device__ __forceinline__ double *qptr(int r) const { return Te + (unsigned)((NANT * maxR + r) * EPW); }
+    __device__ __forceinline__ void append(int R, const double *ve3, const unsigned *, double q) const
+    {
 #pragma unroll
-            for (int k = 0; k < NCOL; k++) c[j][k] = Te[(unsigned)((k * maxR + r) * EPW)];
-        }
+        for (int k = 0; k < NANT; k++) Te[(unsigned)((k * maxR + R) * EPW)] = ve3[k];     // five_add_rule.c:80-81
+        *qptr(R) = q;
     }
 };
 
+template <int NANT>
+struct StoreIdx {
+    static constexpr int W = NANT <= 4 ? 2 : 4, UR = 8;
+    using RecI = typename std::conditional<W == 2, uint2, uint4>::type;
+    RecI *Ti;                                    // tile base + environment slot
+    double *Tq;
+    const double *ve_s;                          // LDS copy of the VE tables [NANT][U]
+    int U, EPW;
+    struct Rec { RecI w; double q; };
+    template <bool NEEDQ>
+    __device__ __forceinline__ Rec load(int r) const
+    {
+        Rec x;
+        x.w = Ti[(unsigned)(r * EPW)];
+        x.q = NEEDQ ? Tq[(unsigned)(r * EPW)] : 0.0;
+        return x;
+    }
+    __device__ __forceinline__ static uint32_t word(const uint2 &w, int i) { return i == 0 ? w.x : w.y; }
+    __device__ __forceinline__ static uint32_t word(const uint4 &w, int i) { return i == 0 ? w.x : (i == 1 ? w.y : (i == 2 ? w.z : w.w)); }
+    __device__ __forceinline__ void decode(const Rec &x, double (&c)[NANT + 1]) const
+    {
+#pragma unroll
+        for (int k = 0; k < NANT; k++) c[k] = ve_s[k * U + ((word(x.w, k >> 1) >> (16 * (k & 1))) & 0xffffu)];
+        c[NANT] = x.q;
+    }
+    __device__ __forceinline__ double *qptr(int r) const { return Tq + (unsigned)(r * EPW); }
+    __device__ __forceinline__ void append(int R, const double *, const unsigned *idx3, double q) const
+    {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < NANT; k++) w[k >> 1] |= (idx3[k] & 0xffffu) << (16 * (k & 1));
+        RecI x;
+        if constexpr (W == 2) { x.x = w[0]; x.y = w[1]; } else { x.x = w[0]; x.y = w[1]; x.z = w[2]; x.w = w[3]; }
+        Ti[(unsigned)(R * EPW)] = x;
+        *qptr(R) = q;
+    }
+};
+
+// The per-lane rule loops are chains of dependent global loads (0.5-1 us each, one or two waves per SIMD): rules are
+// fetched UR at a time into registers, two batches in flight (the next one is requested before the current one is
+// consumed).  Out-of-range slots re-read the last rule (never consumed).
 // for r = first, first + stride, ... < R (in order): f(r, columns of rule r)
-template <int NCOL, class F>
-__device__ __forceinline__ void for_rules(const double *__restrict__ Te, int maxR, int EPW, int first, int stride, int R, F &&f)
+template <bool NEEDQ, int NANT, class STORE, class F>
+__device__ __forceinline__ void for_rules(const STORE &st, int first, int stride, int R, F &&f)
 {
-    RuleBatch<NCOL> a, b;
-    a.load(Te, maxR, EPW, first, stride, R);
-    for (int r0 = first; r0 < R; r0 += 2 * LN_UR * stride) {
-        b.load(Te, maxR, EPW, r0 + LN_UR * stride, stride, R);
+    constexpr int UR = STORE::UR;
+    typename STORE::Rec a[UR], b[UR];
+    auto fetch = [&](typename STORE::Rec(&x)[UR], int r0) {
 #pragma unroll
-        for (int j = 0; j < LN_UR; j++) { const int r = r0 + j * stride; if (r < R) f(r, a.c[j]); }
-        a.load(Te, maxR, EPW, r0 + 2 * LN_UR * stride, stride, R);
+        for (int j = 0; j < UR; j++) {
+            int r = r0 + j * stride;
+            r = r < R ? r : R - 1;
+            r = r < 0 ? 0 : r;
+            x[j] = st.template load<NEEDQ>(r);
+        }
+    };
+    auto consume = [&](const typename STORE::Rec(&x)[UR], int r0) {
 #pragma unroll
-        for (int j = 0; j < LN_UR; j++) { const int r = r0 + (LN_UR + j) * stride; if (r < R) f(r, b.c[j]); }
+        for (int j = 0; j < UR; j++) {
+            const int r = r0 + j * stride;
+            if (r < R) { double c[NANT + 1]; st.decode(x[j], c); f(r, c); }
+        }
+    };
+    fetch(a, first);
+    for (int r0 = first; r0 < R; r0 += 2 * UR * stride) {
+        fetch(b, r0 + UR * stride);
+        consume(a, r0);
+        fetch(a, r0 + 2 * UR * stride);
+        consume(b, r0 + UR * stride);
     }
 }
 
@@ -107,11 +216,11 @@ struct LaneQ {              // one conclusion's raw result
 };
 
 // FIVE_vag_concl's sums for one VE point, all rules, on one lane (sequential, rule order)
-template <int NANT>
-__device__ __forceinline__ LaneQ lane_sweep_q(const double *__restrict__ Te, int maxR, int EPW, int R, const double (&q)[NANT], int p)
+template <int NANT, class STORE>
+__device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const double (&q)[NANT], int p)
 {
     LaneQ o{0.0, 0.0, FRIRL_HIP_NO_HIT};
-    for_rules<NANT + 1>(Te, maxR, EPW, 0, 1, R, [&](int r, const double (&c)[NANT + 1]) {
+    for_rules<true, NANT>(st, 0, 1, R, [&](int r, const double (&c)[NANT + 1]) {
         const double d0 = q[0] - c[0];
         double s = d0 * d0;
 #pragma unroll
@@ -122,27 +231,51 @@ __device__ __forceinline__ LaneQ lane_sweep_q(const double *__restrict__ Te, int
     return o;
 }
 
+struct LanesArgs {
+    const double *u, *ve;        // tables [nant][U]
+    int U;
+    void *T;                     // workspace
+    size_t tq_off;               // index store: byte offset of Tq inside the workspace
+    double *rb;                  // canonical slabs (index store: VE columns of appended rules are written through)
+    uint16_t *uidx;
+    int32_t *nrules;
+    int E, maxR, tiles;
+    int lds_u;                   // universes staged in LDS next to the VE tables
+    int lds_ve;                  // VE tables staged in LDS (always for the index store)
+};
+
 // One wave = 64/G environments.  APL = conclusions per lane: lanes 0..G-2 hold APL actions each ((G-1)*APL >= A), lane
 // G-1 holds Q(s,a).
-template <int NANT, int APL, int G, int WPE>
-__global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                                        double *__restrict__ T, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules,
-                                                                        int E, int maxR, const frirl_hip_agent ag, const frirl_hip_envs ev, int nsteps)
+template <int NANT, int APL, int G, int WPE, bool IDX>
+__global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const LanesArgs la, const frirl_hip_agent ag, const frirl_hip_envs ev, int nsteps)
 {
     constexpr int NS = NANT - 1, EPW = FRIRL_WAVE / G;
-    extern __shared__ double tab_s[];                          // [2][NANT][U] when the tables fit, else unused
+    using STORE = typename std::conditional<IDX, StoreIdx<NANT>, StoreF64<NANT>>::type;
+    extern __shared__ double tab_s[];                          // [NANT][U] VE tables (if lds_ve), then [NANT][U] universes (if lds_u)
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
     __shared__ double ave_s[FRIRL_HIP_MAX_ACTIONS];
-    const int lane = threadIdx.x, sub = lane % G, il = lane / G, base = lane - sub;
-    const int tile = blockIdx.x, e = tile * EPW + il;
-    const bool exists = e < E;
-    const bool in_lds = 2 * sizeof(double) * NANT * (size_t)U <= 16 * 1024;
-    if (in_lds) for (int i = lane; i < NANT * U; i += FRIRL_WAVE) { tab_s[i] = u[i]; tab_s[NANT * U + i] = ve[i]; }
-    for (int i = lane; i < NANT * FRIRL_HIP_MAX_GRID; i += FRIRL_WAVE) grid_s[i] = ag.grid_values[i];
-    if (lane < ag.A) ave_s[lane] = ag.action_ve[lane];
+    const int U = la.U, maxR = la.maxR;
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE, sub = lane % G, il = lane / G, base = lane - sub;
+    const int tile = blockIdx.x * LN_WPB + wave, e = tile * EPW + il;
+    const bool exists = tile < la.tiles && e < la.E;
+    if (la.lds_ve) for (int i = threadIdx.x; i < NANT * U; i += LN_BLOCK) tab_s[i] = la.ve[i];
+    if (la.lds_u) for (int i = threadIdx.x; i < NANT * U; i += LN_BLOCK) tab_s[NANT * U + i] = la.u[i];
+    for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += LN_BLOCK) grid_s[i] = ag.grid_values[i];
+    if ((int)threadIdx.x < ag.A) ave_s[threadIdx.x] = ag.action_ve[threadIdx.x];
     __syncthreads();
-    const double *us = in_lds ? tab_s : u, *ves = in_lds ? tab_s + NANT * U : ve;
-    double *Te = T + (size_t)tile * (NANT + 1) * maxR * EPW + il;          // element (k, r) at Te[(k*maxR + r)*EPW]
+    const double *ves = la.lds_ve ? tab_s : la.ve, *us = la.lds_u ? tab_s + NANT * U : la.u;
+    STORE st;
+    if constexpr (IDX) {
+        st.Ti = reinterpret_cast<typename StoreIdx<NANT>::RecI *>(la.T) + (size_t)tile * maxR * EPW + il;
+        st.Tq = reinterpret_cast<double *>(static_cast<char *>(la.T) + la.tq_off) + (size_t)tile * maxR * EPW + il;
+        st.ve_s = tab_s;
+        st.U = U;
+        st.EPW = EPW;
+    } else {
+        st.Te = static_cast<double *>(la.T) + (size_t)tile * (NANT + 1) * maxR * EPW + il;
+        st.maxR = maxR;
+        st.EPW = EPW;
+    }
     const int p = ag.p > 0 ? ag.p : NANT;
     const bool has_q = (sub == G - 1);
 
@@ -150,19 +283,14 @@ __global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(cons
     int R = 0, fus = 0, steps = 0, status = FRIRL_HIP_UPD_INACTIVE;
     bool active = false;
     uint32_t episode = 0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) states[k] = exists ? ev.states[(size_t)e * NS + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NANT; k++) q_ant[k] = exists ? ev.q_ant[(size_t)e * NANT + k] : 0.0;
     if (exists) {
-#pragma unroll
-        for (int k = 0; k < NS; k++) states[k] = ev.states[(size_t)e * NS + k];
-#pragma unroll
-        for (int k = 0; k < NANT; k++) q_ant[k] = ev.q_ant[(size_t)e * NANT + k];
-        R = nrules[e]; fus = ev.fus[e]; steps = ev.ep_steps[e]; total = ev.ep_reward[e];
+        R = la.nrules[e]; fus = ev.fus[e]; steps = ev.ep_steps[e]; total = ev.ep_reward[e];
         active = ev.done[e] == 0;
         episode = ev.episode ? (uint32_t)ev.episode[e] : 0u;
-    } else {
-#pragma unroll
-        for (int k = 0; k < NS; k++) states[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < NANT; k++) q_ant[k] = 0.0;
     }
     const bool was_active = active;
 
@@ -193,7 +321,7 @@ __global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(cons
                 apt[i] = has_q ? ve1[NS] : ave_s[a < ag.A ? a : 0];
                 sv[i] = 0.0; sw[i] = 0.0; hit[i] = FRIRL_HIP_NO_HIT;
             }
-            for_rules<NANT + 1>(Te, maxR, EPW, 0, 1, R, [&](int r, const double (&c)[NANT + 1]) {
+            for_rules<true, NANT>(st, 0, 1, R, [&](int r, const double (&c)[NANT + 1]) {
                 const double d0 = qsel[0] - c[0];
                 double s = d0 * d0;
 #pragma unroll
@@ -216,7 +344,7 @@ __global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(cons
             for (int i = 0; i < APL; i++) {
                 conc[i] = 0.0;
                 if (i < nacc) {
-                    conc[i] = (hit[i] != FRIRL_HIP_NO_HIT) ? Te[((size_t)NANT * maxR + hit[i]) * EPW] : sv[i] / sw[i];
+                    conc[i] = (hit[i] != FRIRL_HIP_NO_HIT) ? *st.qptr((int)hit[i]) : sv[i] / sw[i];
                     const int a = sub * APL + i;
                     if (!has_q && (a == 0 || bv < conc[i])) { bv = conc[i]; bi = a; }                   // first maximum, max.inl:21
                 }
@@ -261,19 +389,19 @@ __global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(cons
                         same = same && (ve3[k] == ve1[k]);
                     }
                     LaneQ rr{vs1, ws1, hit1};                                                           // :370 (same VE point => same sums)
-                    if (!same) rr = lane_sweep_q<NANT>(Te, maxR, EPW, R, ve3, p);
+                    if (!same) rr = lane_sweep_q<NANT>(st, R, ve3, p);
                     if (rr.hit == FRIRL_HIP_NO_HIT) {                                                   // :373-377 append and leave
                         if (R >= maxR) {
                             status = FRIRL_HIP_UPD_FULL;
                         } else {
                             if (sub == 0) {
+                                st.append(R, ve3, idx3, rr.v / rr.w + qdiff);
 #pragma unroll
                                 for (int k = 0; k < NANT; k++) {
-                                    Te[((size_t)k * maxR + R) * EPW] = ve3[k];                           // five_add_rule.c:80-81
-                                    if (uidx) uidx[((size_t)e * NANT + k) * maxR + R] = (uint16_t)idx3[k];   // :76
+                                    if (IDX) la.rb[((size_t)e * (NANT + 1) + k) * maxR + R] = ve3[k];    // five_add_rule.c:80-81 (canonical slab)
+                                    if (la.uidx) la.uidx[((size_t)e * NANT + k) * maxR + R] = (uint16_t)idx3[k];   // :76
                                     if (ev.rant) ev.rant[((size_t)e * NANT + k) * maxR + R] = rant[k];
                                 }
-                                Te[((size_t)NANT * maxR + R) * EPW] = rr.v / rr.w + qdiff;
                             }
                             R++;
                             fus = 1;
@@ -287,7 +415,7 @@ __global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(cons
                 if (!finished) {
                     const int rules = fus ? R - 1 : R;                                                  // :30-33
                     if (hit1 != FRIRL_HIP_NO_HIT && (ag.skip_rules == 0 || (ag.skip_rules == 1 && (int)hit1 < rules))) {
-                        if (sub == 0) Te[((size_t)NANT * maxR + hit1) * EPW] = qnow + qdiff;             // :55
+                        if (sub == 0) *st.qptr((int)hit1) = qnow + qdiff;                               // :55
                         status = FRIRL_HIP_UPD_EXACT;
                     } else if (ag.skip_rules == 1 && hit1 != FRIRL_HIP_NO_HIT && (int)hit1 == rules) {
                         status = FRIRL_HIP_UPD_SKIPPED;                                                 // :61-63
@@ -295,14 +423,13 @@ __global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(cons
                         if (ag.skip_rules == 0) fus = 0;                                                // :70-73
                         const int r_skip = fus ? R - 1 : -1;                                            // :76,124-126
                         const double iws = 1.0 / ws1;
-                        double *qc = Te + (size_t)NANT * maxR * EPW;
-                        for_rules<NANT>(Te, maxR, EPW, sub, G, R, [&](int r, const double (&c)[NANT]) {      // K6 + K7, rules split over the group
+                        for_rules<false, NANT>(st, sub, G, R, [&](int r, const double (&c)[NANT + 1]) {   // K6 + K7, rules split over the group
                             const double d0 = ve1[0] - c[0];
                             double s = d0 * d0;
 #pragma unroll
                             for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; const double t = d * d; s = s + t; }
                             const double w = inv_dist_pow(s, p) * iws;
-                            if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; qc[(size_t)r * EPW] = qnow + t; }
+                            if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; *st.qptr(r) = qnow + t; }
                         });
                         status = FRIRL_HIP_UPD_SPREAD;
                     }
@@ -328,7 +455,7 @@ __global__ __launch_bounds__(FRIRL_WAVE, WPE) void episode_run_lanes_kernel(cons
     ev.ep_steps[e] = steps;
     ev.ep_reward[e] = total;
     ev.done[e] = active ? 0 : 1;
-    nrules[e] = R;
+    la.nrules[e] = R;
 }
 
 }  // namespace frirl
@@ -344,28 +471,51 @@ extern "C" size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32
     if (nant < 1 || E < 1 || maxR < 1 || A < 1) return 0;
     const int epw = FRIRL_WAVE / lanes_group(A);
     const size_t tiles = ((size_t)E + epw - 1) / epw;
-    return tiles * epw * (size_t)(nant + 1) * (size_t)maxR * sizeof(double);
+    return tiles * epw * (size_t)(nant + 1) * (size_t)maxR * sizeof(double);     // f64 store; the index store needs less
 }
 
-template <int N, int APL, int G>
-static void launch_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev, int nsteps,
-                         double *T, hipStream_t s)
+// Measured crossover against the per-environment kernels (profiles/r01_learning.md): the lane groups win once they give
+// the chip >= 1024 waves, and always for the 3-antecedent demo (rule bases of <= ~110 rules).
+extern "C" int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A)
 {
-    constexpr int EPW = FRIRL_WAVE / G;
-    const int tiles = (b->E + EPW - 1) / EPW;
-    const size_t tab = 2 * sizeof(double) * N * (size_t)t->U;
-    const size_t dyn = tab <= 16 * 1024 ? tab : 0;
-    hipLaunchKernelGGL(frirl::lanes_import_kernel, dim3(tiles, N + 1), dim3(256), 0, s, b->rb, b->nrules, b->E, N + 1, b->maxR, EPW, T);
-    // registers: 2 waves per SIMD keep both rule batches and the environment state in VGPRs; beyond ~2048 waves (more
-    // environments than that can hold at once) 4 waves per SIMD with a few cold values in scratch win
-    int wpe = tiles > 2048 ? 4 : 2;
+    if (nant < 1 || E < 1 || A < 1) return 0;
+    const int epw = FRIRL_WAVE / lanes_group(A);
+    return ((E + epw - 1) / epw >= 1024 || nant <= 3) ? 1 : 0;
+}
+
+template <int N, int APL, int G, bool IDX>
+static void launch_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev, int nsteps,
+                         void *T, hipStream_t s)
+{
+    constexpr int EPW = FRIRL_WAVE / G, W = N <= 4 ? 2 : 4;
+    frirl::LanesArgs la;
+    la.u = t->u; la.ve = t->ve; la.U = t->U; la.T = T; la.rb = b->rb; la.uidx = b->uidx; la.nrules = b->nrules; la.E = b->E; la.maxR = b->maxR;
+    la.tiles = (b->E + EPW - 1) / EPW;
+    const size_t tab = sizeof(double) * N * (size_t)t->U;
+    la.lds_ve = IDX ? 1 : (2 * tab <= 32 * 1024);
+    la.lds_u = 2 * tab <= 32 * 1024;
+    la.tq_off = (size_t)la.tiles * EPW * b->maxR * W * sizeof(uint32_t);
+    const size_t dyn = (la.lds_ve ? tab : 0) + (la.lds_u ? tab : 0);
+    if (IDX)
+        hipLaunchKernelGGL(frirl::lanes_import_idx_kernel, dim3(la.tiles), dim3(256), 0, s, b->rb, b->uidx, b->nrules, b->E, N, b->maxR, EPW, W,
+                           static_cast<uint32_t *>(T), reinterpret_cast<double *>(static_cast<char *>(T) + la.tq_off));
+    else
+        hipLaunchKernelGGL(frirl::lanes_import_kernel, dim3(la.tiles, N + 1), dim3(256), 0, s, b->rb, b->nrules, b->E, N + 1, b->maxR, EPW, static_cast<double *>(T));
+    // registers: 2 waves per SIMD keep both rule batches and the environment state in VGPRs; for the 3-antecedent kernels
+    // with more environments than that can hold at once, 4 waves per SIMD (a few cold values in scratch) hide more
+    // latency (measured: mountaincar x 65 536 agents 1.25 -> 1.54e9 env-steps/s; the 5-antecedent kernels lose)
+    const int blocks = (la.tiles + frirl::LN_WPB - 1) / frirl::LN_WPB;
+    int wpe = (la.tiles > 2048 && N <= 3) ? 4 : 2;
     if (const char *e = getenv("FRIRL_HIP_LANES_WPE")) { const int v = atoi(e); if (v == 2 || v == 3 || v == 4) wpe = v; }
-#define LANES_GO(W)                                                                                                                                \
-    hipLaunchKernelGGL((frirl::episode_run_lanes_kernel<N, APL, G, W>), dim3(tiles), dim3(FRIRL_WAVE), dyn, s, t->u, t->ve, t->U, T, b->uidx, b->nrules, \
-                       b->E, b->maxR, *ag, *ev, nsteps)
+#define LANES_GO(WPE) hipLaunchKernelGGL((frirl::episode_run_lanes_kernel<N, APL, G, WPE, IDX>), dim3(blocks), dim3(frirl::LN_BLOCK), dyn, s, la, *ag, *ev, nsteps)
     if (wpe == 4) LANES_GO(4); else if (wpe == 3) LANES_GO(3); else LANES_GO(2);
 #undef LANES_GO
-    hipLaunchKernelGGL(frirl::lanes_export_kernel, dim3(tiles, N + 1), dim3(256), 0, s, b->rb, b->nrules, b->E, N + 1, b->maxR, EPW, T);
+    if (IDX)          // antecedents of appended rules were written through; only the consequents come back
+        hipLaunchKernelGGL(frirl::lanes_export_kernel, dim3(la.tiles, 1), dim3(256), 0, s, b->rb, b->nrules, b->E, N + 1, b->maxR, EPW,
+                           reinterpret_cast<const double *>(static_cast<char *>(T) + la.tq_off), 1, N);
+    else
+        hipLaunchKernelGGL(frirl::lanes_export_kernel, dim3(la.tiles, N + 1), dim3(256), 0, s, b->rb, b->nrules, b->E, N + 1, b->maxR, EPW,
+                           static_cast<const double *>(T), N + 1, 0);
 }
 
 extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
@@ -377,16 +527,19 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     const size_t need = frirl_hip_lanes_workspace_bytes(t->nant, b->E, b->maxR, agent->A);
     if (workspace_bytes < need) { set_error("frirl_hip_episode_run_lanes: workspace %zu B < %zu B (frirl_hip_lanes_workspace_bytes)", workspace_bytes, need); return FRIRL_HIP_EINVAL; }
     hipStream_t s = as_stream(stream);
-    double *T = static_cast<double *>(workspace);
     const int G = lanes_group(agent->A), apl = lanes_apl(agent->A);
-#define RUN(N)                                                                     \
-    do {                                                                           \
-        if (G == 4) launch_lanes<N, 1, 4>(t, b, agent, envs, nsteps, T, s);        \
-        else if (apl == 1) launch_lanes<N, 1, 8>(t, b, agent, envs, nsteps, T, s); \
-        else if (apl == 3) launch_lanes<N, 3, 8>(t, b, agent, envs, nsteps, T, s); \
-        else launch_lanes<N, 5, 8>(t, b, agent, envs, nsteps, T, s);               \
+    // index store when the caller keeps the 16-bit index mirror and the VE tables fit in LDS (48 KiB)
+    bool idx = b->uidx != nullptr && sizeof(double) * t->nant * (size_t)t->U <= 48 * 1024 && t->U <= 65536;
+    if (const char *e = getenv("FRIRL_HIP_NO_UIDX")) if (atoi(e) == 1) idx = false;
+#define RUN(N, IDX)                                                                               \
+    do {                                                                                          \
+        if (G == 4) launch_lanes<N, 1, 4, IDX>(t, b, agent, envs, nsteps, workspace, s);          \
+        else if (apl == 1) launch_lanes<N, 1, 8, IDX>(t, b, agent, envs, nsteps, workspace, s);   \
+        else if (apl == 3) launch_lanes<N, 3, 8, IDX>(t, b, agent, envs, nsteps, workspace, s);   \
+        else launch_lanes<N, 5, 8, IDX>(t, b, agent, envs, nsteps, workspace, s);                 \
     } while (0)
-    if (t->nant == 3) RUN(3); else RUN(5);
+    if (t->nant == 3) { if (idx) RUN(3, true); else RUN(3, false); }
+    else { if (idx) RUN(5, true); else RUN(5, false); }
 #undef RUN
     return check_launch("frirl_hip_episode_run_lanes");
 }

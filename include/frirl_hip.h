@@ -292,6 +292,8 @@ int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases
  * inserted rules) and distances are those of the step kernel; interpolated Q agrees to ~1e-15 (different summation
  * order than the tree of the per-environment kernels, same as the reference's). */
 size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
+/* 1 when the lane-group form is expected to beat the per-environment kernels for this batch shape (measured crossover) */
+int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A);
 int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                                 const frirl_hip_envs *envs, int32_t nsteps, void *workspace, size_t workspace_bytes, void *stream);
 

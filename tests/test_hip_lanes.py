@@ -9,8 +9,17 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["index-store", "f64-store"])
+def store(request, monkeypatch):
+    """Both rule stores of the lane-group kernel: packed 16-bit universe indices + LDS tables (default when the batch keeps
+    the index mirror) and plain f64 columns (FRIRL_HIP_NO_UIDX=1)."""
+    if request.param == "f64-store":
+        monkeypatch.setenv("FRIRL_HIP_NO_UIDX", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("env,episodes,steps,rules", [("mountaincar", 29, 15548, 110), ("cartpole", 58, 33002, 182), ("acrobot", 110, 21207, 367)])
-def test_lane_group_training_reaches_the_oracle_rule_base(env, episodes, steps, rules):
+def test_lane_group_training_reaches_the_oracle_rule_base(env, episodes, steps, rules, store):
     """E = 21 agents (ragged last wave) learn from the corner rule base through the lane-group kernel; every agent must
     end exactly where the oracle ends: episodes, total steps, rule count, antecedents and order bit-exact, Q <= 1e-9."""
     import torch
@@ -44,7 +53,7 @@ def test_lane_group_training_reaches_the_oracle_rule_base(env, episodes, steps, 
 
 
 @pytest.mark.parametrize("env", ["mountaincar", "acrobot", "cartpole"])
-def test_lane_group_steps_equal_step_kernel(env):
+def test_lane_group_steps_equal_step_kernel(env, store):
     """Same start, per-environment start states (different trajectories, ragged episode ends): chunks of lane-group
     steps vs the same number of frirl_hip_episode_step launches -- states, actions, rule counts, status, step counts
     identical; Q within 1e-10."""

@@ -8,7 +8,7 @@ import torch, frirl_amd
 env = sys.argv[1] if len(sys.argv) > 1 else "mountaincar"
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 diversify = len(sys.argv) > 3 and sys.argv[3] == "div"
-lanes = os.environ.get("LANES", "0") == "1"      # lane-group kernel (frirl_hip_episode_run_lanes)
+lanes = {"1": True, "0": False}.get(os.environ.get("LANES", ""), None)      # force / forbid the lane-group kernel; default: library heuristic
 dev = torch.device("cuda", 0)
 d = frirl_amd.demo_describe(env)
 start = None
