@@ -317,6 +317,8 @@ extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_h
     if (rc) return rc;
     if (!agent || !ro || !ro->steps || !ro->reward || !agent->grid_values || !agent->action_ve) { set_error("frirl_hip_rollout_shared: NULL argument"); return FRIRL_HIP_EINVAL; }
     if (agent->A < 1 || agent->A > FRIRL_HIP_MAX_ACTIONS || agent->max_steps < 0) { set_error("frirl_hip_rollout_shared: A=%d / max_steps=%d out of range", agent->A, agent->max_steps); return FRIRL_HIP_EINVAL; }
+    for (int k = 0; k < t->nant; k++)
+        if (agent->grid_len[k] < 1 || agent->grid_len[k] > FRIRL_HIP_MAX_GRID) { set_error("frirl_hip_rollout_shared: grid_len[%d]=%d outside 1..%d", k, agent->grid_len[k], FRIRL_HIP_MAX_GRID); return FRIRL_HIP_EINVAL; }
     if ((ro->exclude_mask == nullptr) != (ro->rule_slot == nullptr)) { set_error("frirl_hip_rollout_shared: exclude_mask and rule_slot go together"); return FRIRL_HIP_EINVAL; }
     if (agent->env_kind == FRIRL_HIP_ENV_MOUNTAINCAR ? t->nant != 3 : t->nant != 5) {
         set_error("frirl_hip_rollout_shared: env_kind %d does not match nant=%d", agent->env_kind, t->nant);

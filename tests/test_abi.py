@@ -72,3 +72,44 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(frirl_amd, "HIP_LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(frirl_amd.FrirlHipError):
         frirl_amd.lib()
+
+
+def test_rollout_and_reduce_struct_layouts():
+    R, Q = frirl_amd.RolloutDesc, frirl_amd.ReduceResult
+    assert C.sizeof(R) == 56 and R.exclude_mask.offset == 8 and R.rule_slot.offset == 16 and R.steps.offset == 24 and R.final_states.offset == 48
+    assert C.sizeof(Q) == 32 and Q.rules_after.offset == 4 and Q.rollouts.offset == 12 and Q.steps_incremental.offset == 16 and Q.reward.offset == 24
+
+
+def test_shared_and_lane_entry_points_refuse_without_gpu(lib):
+    """The evaluation / reduction / lane-group entry points validate their arguments and, on a host without a GPU, return
+    FRIRL_HIP_ENODEV instead of computing anything (no CPU fallback anywhere in the product)."""
+    import torch
+    buf = (C.c_double * 8192)()
+    addr = (C.addressof(buf) + 15) & ~15
+    t = frirl_amd.Tables(3, 41, addr, addr)
+    b1 = frirl_amd.RuleBases(1, 8, addr, addr)
+    b2 = frirl_amd.RuleBases(2, 8, addr, addr)
+    # argument validation comes first and does not need a device
+    assert lib.five_hip_vag_concl_shared(C.byref(t), C.byref(b2), 0, 4, addr, addr, addr, None) == -2 and b"E == 1" in lib.frirl_hip_last_error()
+    ag = frirl_amd.AgentDesc()
+    ag.A, ag.env_kind, ag.max_steps, ag.grid_values, ag.action_ve = 3, 0, 10, addr, addr
+    for k in range(3):
+        ag.grid_len[k] = 3
+    res = frirl_amd.ReduceResult()
+    assert lib.frirl_hip_lanes_workspace_bytes(3, 100, 64, 3) == 112 * 4 * 64 * 8          # 7 tiles of 16 environments, f64 store
+    assert lib.frirl_hip_lanes_preferred(3, 10, 3) == 1 and lib.frirl_hip_lanes_preferred(5, 8192, 3) == 0 and lib.frirl_hip_lanes_preferred(5, 65536, 3) == 1
+    if torch.cuda.is_available():
+        assert lib.frirl_hip_reduce_shared(C.byref(t), C.byref(b1), C.byref(ag), None, 3, 0.0, 0, None, C.byref(res), None) == -2
+        assert lib.frirl_hip_reduce_shared(C.byref(t), C.byref(b1), C.byref(ag), None, 1, 0.0, 13, None, C.byref(res), None) == -2
+        pytest.skip("GPU present: the ENODEV path is exercised on CPU-only hosts")
+    ro = frirl_amd.RolloutDesc()
+    ro.steps, ro.reward = addr, addr
+    ev = frirl_amd.EnvsDesc()
+    ev.states = ev.q_ant = ev.fus = ev.done = ev.ep_steps = ev.ep_reward = addr
+    for rc in (lib.five_hip_vag_concl_shared(C.byref(t), C.byref(b1), 0, 4, addr, addr, addr, None),
+               lib.frirl_hip_get_best_action_shared(C.byref(t), C.byref(b1), 0, 4, addr, addr, 3, addr, addr, None),
+               lib.frirl_hip_rollout_shared(C.byref(t), C.byref(b1), C.byref(ag), 4, C.byref(ro), None),
+               lib.frirl_hip_reduce_shared(C.byref(t), C.byref(b1), C.byref(ag), None, 1, 0.0, 0, None, C.byref(res), None),
+               lib.frirl_hip_episode_run_lanes(C.byref(t), C.byref(b1), C.byref(ag), C.byref(ev), 5, addr, 1 << 20, None)):
+        assert rc == -1, lib.frirl_hip_last_error()
+        assert b"no CPU fallback" in lib.frirl_hip_last_error()
