@@ -523,6 +523,7 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
 {
     int rc = frirl_check_episode(t, b, agent, envs, "frirl_hip_episode_run_lanes");
     if (rc) return rc;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) { set_error("frirl_hip_episode_run_lanes: workspace must be 16-byte aligned"); return FRIRL_HIP_EINVAL; }
     if (nsteps < 0 || !workspace) { set_error("frirl_hip_episode_run_lanes: nsteps=%d / workspace=%p", nsteps, workspace); return FRIRL_HIP_EINVAL; }
     const size_t need = frirl_hip_lanes_workspace_bytes(t->nant, b->E, b->maxR, agent->A);
     if (workspace_bytes < need) { set_error("frirl_hip_episode_run_lanes: workspace %zu B < %zu B (frirl_hip_lanes_workspace_bytes)", workspace_bytes, need); return FRIRL_HIP_EINVAL; }
