@@ -26,20 +26,21 @@ __device__ __forceinline__ double pow_int(double b, int p)
 // Shepard weight 1/d^p from the SQUARED distance s = d^2 > 0 (reference: wi = 1.0 / fast_pow(fast_abs(d), p),
 // FIVEVagConcl.c:226, with d = sqrt(s)).  The reference's sqrt + p-1 multiplies + divide cost ~70 FP64
 // instructions per rule on CDNA4 (software sqrt and divide) and make the Q sweeps ALU-bound; here
-// y = rsqrt(s) (v_rsq_f64) is refined by two Newton steps (relative error ~1e-16, i.e. the same size as the
+// y = rsqrt(s) (v_rsq_f64) is refined by one third-order step (relative error ~1e-16, i.e. the same size as the
 // rounding of the reference's own sqrt/pow/divide chain) and raised to p by multiplication: ~20 instructions.
 // Exact-hit detection does not depend on it (d == 0 <=> s == 0).  Interpolated Q values are contractually
 // within 1e-6 relative of the reference (include/frirl_hip.h); materialised distances (five_hip_rule_distance)
 // keep the IEEE sqrt and stay bit-exact.
 __device__ __forceinline__ double inv_dist_pow(double s, int p)
 {
+    // v_rsq_f64 is good to 5.2e-8; ONE third-order step y (1 + e/2 + 3 e^2/8), e = 1 - s y^2, brings it to 1.4e-16
+    // (measured, tools/exp/rsq_prec.hip: the same as two Newton steps) in 5 instead of 8 FP64 instructions
     double y = __builtin_amdgcn_rsq(s);
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const double t = s * y;
-        const double e = __fma_rn(-t, y, 1.0);
-        y = __fma_rn(0.5 * y, e, y);
-    }
+    const double t = s * y;
+    const double e = __fma_rn(-t, y, 1.0);
+    const double c = __fma_rn(0.375, e, 0.5);
+    const double ce = c * e;
+    y = __fma_rn(y, ce, y);
     double w = y;
     for (int i = 1; i < p; i++) w = w * y;
     return w;
