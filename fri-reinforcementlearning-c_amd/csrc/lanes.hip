@@ -226,7 +226,7 @@ __device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const doub
 #pragma unroll
         for (int k = 1; k < NANT; k++) { const double d = q[k] - c[k]; const double t = d * d; s = s + t; }
         if (s == 0.0) { if (o.hit == FRIRL_HIP_NO_HIT) o.hit = (unsigned)r; }
-        else { const double wi = inv_dist_pow(s, p); const double t = wi * c[NANT]; o.v = o.v + t; o.w = o.w + wi; }
+        else { const double wi = inv_dist_pow<true>(s, p); const double t = wi * c[NANT]; o.v = o.v + t; o.w = o.w + wi; }
     });
     return o;
 }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                         const double f = ea * ea;
                         const double d2 = f + s;
                         if (d2 == 0.0) { if (hit[i] == FRIRL_HIP_NO_HIT) hit[i] = (unsigned)r; }
-                        else { const double wi = inv_dist_pow(d2, p); const double t = wi * cq; sv[i] = sv[i] + t; sw[i] = sw[i] + wi; }
+                        else { const double wi = inv_dist_pow<true>(d2, p); const double t = wi * cq; sv[i] = sv[i] + t; sw[i] = sw[i] + wi; }
                     }
                 }
             });
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                             double s = d0 * d0;
 #pragma unroll
                             for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; const double t = d * d; s = s + t; }
-                            const double w = inv_dist_pow(s, p) * iws;
+                            const double w = inv_dist_pow<true>(s, p) * iws;
                             if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; *st.qptr(r) = qnow + t; }
                         });
                         status = FRIRL_HIP_UPD_SPREAD;

@@ -69,8 +69,10 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
             if (EXCL) for (int r = threadIdx.x; r < SH_TILE; r += SH_BLOCK) tl.slot[r] = (r < n) ? slot_g[r0 + r] : (uint8_t)255;
             __syncthreads();
             if (live && nacc > 0) {
+                // branch-free body (selects on the exact-hit test and on the try-remove mask): straight-line code per rule
                 for (int r = 0; r < n; r++) {
-                    if (EXCL) { const unsigned sl = tl.slot[r]; if (sl < 32u && ((mask >> sl) & 1u)) continue; }
+                    bool valid = true;
+                    if (EXCL) { const unsigned sl = tl.slot[r]; valid = !(sl < 32u && ((mask >> sl) & 1u)); }
                     double d0 = q[0] - tl.col[r];
                     double s = d0 * d0;
 #pragma unroll
@@ -84,13 +86,21 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                                 const double e = tl.ave[a0 + a] - va;
                                 const double f = e * e;
                                 const double d2 = f + s;
-                                if (d2 == 0.0) { if (sh[a] == FRIRL_HIP_NO_HIT) sh[a] = (unsigned)(r0 + r); }
-                                else { const double wi = inv_dist_pow(d2, p); const double t = wi * cq; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
+                                const bool z = d2 == 0.0;
+                                const double wi = (z || !valid) ? 0.0 : inv_dist_pow<true>(d2, p);      // an exact hit adds +0.0
+                                const double t = wi * cq;
+                                sv[a] = sv[a] + t;
+                                sw[a] = sw[a] + wi;
+                                sh[a] = (z && valid && sh[a] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[a];
                             }
                         }
                     } else {
-                        if (s == 0.0) { if (sh[0] == FRIRL_HIP_NO_HIT) sh[0] = (unsigned)(r0 + r); }
-                        else { const double wi = inv_dist_pow(s, p); const double t = wi * cq; sv[0] = sv[0] + t; sw[0] = sw[0] + wi; }
+                        const bool z = s == 0.0;
+                        const double wi = (z || !valid) ? 0.0 : inv_dist_pow<true>(s, p);
+                        const double t = wi * cq;
+                        sv[0] = sv[0] + t;
+                        sw[0] = sw[0] + wi;
+                        sh[0] = (z && valid && sh[0] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[0];
                     }
                 }
             }

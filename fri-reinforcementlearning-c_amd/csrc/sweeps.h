@@ -31,6 +31,7 @@ __device__ __forceinline__ double pow_int(double b, int p)
 // Exact-hit detection does not depend on it (d == 0 <=> s == 0).  Interpolated Q values are contractually
 // within 1e-6 relative of the reference (include/frirl_hip.h); materialised distances (five_hip_rule_distance)
 // keep the IEEE sqrt and stay bit-exact.
+template <bool UNROLLED_POWERS = false>
 __device__ __forceinline__ double inv_dist_pow(double s, int p)
 {
     // v_rsq_f64 is good to 5.2e-8; ONE third-order step y (1 + e/2 + 3 e^2/8), e = 1 - s y^2, brings it to 1.4e-16
@@ -41,6 +42,14 @@ __device__ __forceinline__ double inv_dist_pow(double s, int p)
     const double c = __fma_rn(0.375, e, 0.5);
     const double ce = c * e;
     y = __fma_rn(y, ce, y);
+    // y^p.  UNROLLED_POWERS: the demos' powers (p = nant = 3, 5) without a loop -- a data-dependent trip count costs a
+    // wave its branch latency on every rule when only one or two waves share a SIMD (lane-group / shared-base kernels:
+    // +6..9 %); the many-wave per-environment sweeps keep the plain loop (measured 8 % faster there)
+    if (UNROLLED_POWERS) {
+        const double y2 = y * y;
+        if (p == 3) return y2 * y;
+        if (p == 5) return (y2 * y2) * y;
+    }
     double w = y;
     for (int i = 1; i < p; i++) w = w * y;
     return w;
