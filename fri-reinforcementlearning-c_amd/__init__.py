@@ -116,6 +116,8 @@ SIGNATURES = {
     "frirl_hip_batch_train": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "frirl_hip_batch_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "frirl_hip_batch_get_rulebase": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _DP, _DP]),
+    "frirl_hip_batch_save_rulebases": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "frirl_hip_batch_load_rulebases": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "frirl_hip_batch_reduce": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, C.c_double, C.c_int, C.POINTER(ReduceResult)]),
     # single rule base, host pointers (what the ANSI-C drop-in library calls)
     "five_hip_mirror_create": (C.c_void_p, [C.c_int32, C.c_int32, _DP, _DP, C.c_int32, C.c_int32]),

@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #include "device_common.h"
@@ -242,4 +244,86 @@ extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strateg
     one.nrules = b->d_nrules + e;
     if (one.uidx) one.uidx = b->rb.uidx + (size_t)e * n * M;
     return frirl_hip_reduce_shared(&b->t, &one, &b->agent, b->d_rant + (size_t)e * n * M, strategy, reward_tolerance, depth, nullptr, result, b->s);
+}
+
+// ---- batched rule-base I/O in the reference's .frirlrb.bin record format (frirl_utils.c:151-281) ------------------------
+extern "C" int frirl_hip_batch_save_rulebases(frirl_hip_batch *b, const char *path)
+{
+    if (!b || !path) { set_error("frirl_hip_batch_save_rulebases: bad arguments"); return FRIRL_HIP_EINVAL; }
+    const size_t n = b->nant, M = b->maxR, E = b->E;
+    std::vector<int32_t> nr(E);
+    std::vector<double> rant(E * n * M), rb(E * (n + 1) * M);
+    BCHK(hipStreamSynchronize(b->s), "save sync");
+    BCHK(hipMemcpy(nr.data(), b->d_nrules, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "nrules download");
+    BCHK(hipMemcpy(rant.data(), b->d_rant, sizeof(double) * rant.size(), hipMemcpyDeviceToHost), "rant download");
+    BCHK(hipMemcpy(rb.data(), b->d_rb, sizeof(double) * rb.size(), hipMemcpyDeviceToHost), "rb download");
+    FILE *fp = fopen(path, "wb");
+    if (!fp) { set_error("frirl_hip_batch_save_rulebases: cannot open %s", path); return FRIRL_HIP_EINVAL; }
+    std::vector<double> rec;
+    bool ok = true;
+    for (size_t e = 0; e < E && ok; e++) {
+        const int32_t R = nr[e];
+        rec.resize((size_t)R * (n + 1));
+        for (int r = 0; r < R; r++) {
+            for (size_t k = 0; k < n; k++) rec[(size_t)r * (n + 1) + k] = rant[(e * n + k) * M + r];
+            rec[(size_t)r * (n + 1) + n] = rb[(e * (n + 1) + n) * M + r];
+        }
+        ok = fwrite(&R, sizeof R, 1, fp) == 1 && (R == 0 || fwrite(rec.data(), sizeof(double), rec.size(), fp) == rec.size());
+    }
+    ok = (fclose(fp) == 0) && ok;
+    if (!ok) { set_error("frirl_hip_batch_save_rulebases: write to %s failed", path); return FRIRL_HIP_EINVAL; }
+    return FRIRL_HIP_OK;
+}
+
+extern "C" int frirl_hip_batch_load_rulebases(frirl_hip_batch *b, const char *path, int32_t *records_read)
+{
+    if (!b || !path) { set_error("frirl_hip_batch_load_rulebases: bad arguments"); return FRIRL_HIP_EINVAL; }
+    const size_t n = b->nant, M = b->maxR, E = b->E;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { set_error("frirl_hip_batch_load_rulebases: cannot open %s", path); return FRIRL_HIP_EINVAL; }
+    // parse and validate the whole file before touching the batch
+    std::vector<std::vector<double>> recs;
+    for (;;) {
+        int32_t R = 0;
+        const size_t got = fread(&R, 1, sizeof R, fp);
+        if (got == 0) break;                                   // clean end of file
+        if (got != sizeof R) { fclose(fp); set_error("frirl_hip_batch_load_rulebases: %s: truncated record header", path); return FRIRL_HIP_EINVAL; }
+        if (R < 1 || (size_t)R > M) { fclose(fp); set_error("frirl_hip_batch_load_rulebases: %s: record %zu has %d rules (capacity %zu)", path, recs.size(), R, M); return FRIRL_HIP_EINVAL; }
+        std::vector<double> rec((size_t)R * (n + 1));
+        if (fread(rec.data(), sizeof(double), rec.size(), fp) != rec.size()) { fclose(fp); set_error("frirl_hip_batch_load_rulebases: %s: record %zu is truncated", path, recs.size()); return FRIRL_HIP_EINVAL; }
+        for (double v : rec) if (!(v - v == 0.0)) { fclose(fp); set_error("frirl_hip_batch_load_rulebases: %s: record %zu holds a non-finite value", path, recs.size()); return FRIRL_HIP_EINVAL; }
+        recs.push_back(std::move(rec));
+        if (recs.size() == E) break;
+    }
+    fclose(fp);
+    if (recs.empty()) { set_error("frirl_hip_batch_load_rulebases: %s holds no rule base", path); return FRIRL_HIP_EINVAL; }
+    if (records_read) *records_read = (int32_t)recs.size();
+    // rebuild: nrules = 0, then rule r of every agent through FIVE_add_rule (agents whose record is shorter sit out)
+    BCHK(hipMemsetAsync(b->d_nrules, 0, sizeof(int32_t) * E, b->s), "nrules reset");
+    BCHK(hipMemsetAsync(b->d_fus, 0, sizeof(int32_t) * E, b->s), "fus reset");            // frirl_utils.c:262
+    size_t rmax = 0;
+    for (size_t e = 0; e < E; e++) { const auto &rec = recs[e < recs.size() ? e : recs.size() - 1]; rmax = std::max(rmax, rec.size() / (n + 1)); }
+    std::vector<double> stage(E * (n + 1));
+    std::vector<uint8_t> act(E);
+    uint8_t *d_act = nullptr;
+    BCHK(hipMalloc((void **)&d_act, E), "active mask");
+    int rc = FRIRL_HIP_OK;
+    for (size_t r = 0; r < rmax && rc == FRIRL_HIP_OK; r++) {
+        for (size_t e = 0; e < E; e++) {
+            const auto &rec = recs[e < recs.size() ? e : recs.size() - 1];
+            const bool has = r < rec.size() / (n + 1);
+            act[e] = has ? 1 : 0;
+            for (size_t k = 0; k < n; k++) stage[e * n + k] = has ? rec[r * (n + 1) + k] : 0.0;
+            stage[E * n + e] = has ? rec[r * (n + 1) + n] : 0.0;
+        }
+        if (hipMemcpyAsync(b->d_tmp, stage.data(), sizeof(double) * E * (n + 1), hipMemcpyHostToDevice, b->s) != hipSuccess ||
+            hipMemcpyAsync(d_act, act.data(), E, hipMemcpyHostToDevice, b->s) != hipSuccess) { set_error("frirl_hip_batch_load_rulebases: upload failed"); rc = FRIRL_HIP_ELAUNCH; break; }
+        rc = five_hip_add_rule(&b->t, &b->rb, b->d_tmp, b->d_tmp + E * n, d_act, b->d_rant, nullptr, b->s);
+        if (rc == FRIRL_HIP_OK && hipStreamSynchronize(b->s) != hipSuccess) { set_error("frirl_hip_batch_load_rulebases: add_rule failed"); rc = FRIRL_HIP_ELAUNCH; }
+    }
+    (void)hipFree(d_act);
+    if (rc) return rc;
+    if ((rc = frirl_hip_convergence_init(&b->rb, b->nant, &b->conv, b->s))) return rc;
+    BCHK(hipStreamSynchronize(b->s), "load sync");
+    return FRIRL_HIP_OK;
 }

@@ -22,12 +22,15 @@ int main(int argc, char **argv)
     const char *env = "mountaincar";
     char name[128];
     int i, max_episodes = 0, fargc = 0, reduce = 0, agents = 0;
+    const char *load_bin = NULL, *save_bin = NULL;
     char *fargv[16];
     fargv[fargc++] = argv[0];
     for (i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--env") && i + 1 < argc) env = argv[++i];
         else if (!strcmp(argv[i], "--max-episodes") && i + 1 < argc) max_episodes = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--agents") && i + 1 < argc) agents = atoi(argv[++i]);      /* batched: N independent agents on the GPU */
+        else if (!strcmp(argv[i], "--load") && i + 1 < argc) load_bin = argv[++i];             /* batched: start from a .frirlrb.bin file */
+        else if (!strcmp(argv[i], "--save") && i + 1 < argc) save_bin = argv[++i];             /* batched: all agents' rule bases to one .bin */
         else if (!strcmp(argv[i], "--reduce") && i + 1 < argc) reduce = atoi(argv[++i]);   /* construct, then reduce with strategy 1|2 */
         else if (fargc < 15) fargv[fargc++] = argv[i];
     }
@@ -35,7 +38,8 @@ int main(int argc, char **argv)
     if (agents > 0) {
         snprintf(name, sizeof name, "%s.batch.frirlrb.txt", env);
         if (reduce == 1 || reduce == 2) snprintf(name, sizeof name, "%s.batch.reduced%d.frirlrb.txt", env, reduce);
-        return frirl_demo_batch_run_reduce(env, agents, max_episodes > 0 ? max_episodes : fr.max_episodes, reduce, name, 1) == agents ? 0 : 3;
+        if (load_bin) return frirl_demo_batch_run_ex(env, agents, 2, reduce, load_bin, save_bin, name, 1) >= 0 ? 0 : 3;
+        return frirl_demo_batch_run_ex(env, agents, max_episodes > 0 ? max_episodes : fr.max_episodes, reduce, NULL, save_bin, name, 1) == agents ? 0 : 3;
     }
     if (frirl_demo_setup(&fr, env) != 0) return 2;
     if (max_episodes > 0) fr.max_episodes = max_episodes;

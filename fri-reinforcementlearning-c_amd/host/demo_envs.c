@@ -250,6 +250,12 @@ int frirl_demo_batch_run(const char *env, int agents, int max_episodes, const ch
 
 int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, int reduce_strategy, const char *out_txt, int verbose)
 {
+    return frirl_demo_batch_run_ex(env, agents, max_episodes, reduce_strategy, NULL, NULL, out_txt, verbose);
+}
+
+int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int reduce_strategy, const char *load_bin, const char *save_bin,
+                            const char *out_txt, int verbose)
+{
     int ns, U, A, max_steps, nant, k, j, R0, episodes = 0, rc;
     double *u, *ve, *grid, *action_ve, *rant0, *rconc0;
     int grid_len[FRIRL_HIP_MAX_NANT];
@@ -279,9 +285,19 @@ int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, i
     d.agent.env_kind = !strcmp(env, "mountaincar") ? FRIRL_HIP_ENV_MOUNTAINCAR : (!strcmp(env, "cartpole") ? FRIRL_HIP_ENV_CARTPOLE : FRIRL_HIP_ENV_ACROBOT);
     for (k = 0; k < nant; k++) { d.agent.grid_len[k] = grid_len[k]; d.agent.grid_div[k] = grid_div[k]; d.agent.values_def[k] = values_def[k]; }
     d.agent.grid_values = grid; d.agent.action_ve = action_ve;
+    d.agent.evaluate = load_bin ? 1 : 0;          /* loaded rule bases are replayed greedily, not trained (frirl_test_run.c:66-70) */
     b = frirl_hip_batch_create(&d);
     if (!b) five_dropin_fatal("frirl_demo_batch_run(create)", FRIRL_HIP_ENODEV);
-    rc = frirl_hip_batch_train(b, max_episodes, &episodes);
+    if (load_bin) {
+        int32_t nrec = 0;
+        rc = frirl_hip_batch_load_rulebases(b, load_bin, &nrec);
+        if (rc) five_dropin_fatal("frirl_demo_batch_run(load)", rc);
+        if (verbose) printf("batch %s: loaded %d rule base record(s) from %s\n", env, (int)nrec, load_bin);
+        rc = frirl_hip_batch_episode(b);          /* one greedy episode per agent */
+        episodes = 1;
+    } else {
+        rc = frirl_hip_batch_train(b, max_episodes, &episodes);
+    }
     if (rc) five_dropin_fatal("frirl_demo_batch_run(train)", rc);
     rc = frirl_hip_batch_stats(b, &st);
     if (rc) five_dropin_fatal("frirl_demo_batch_run(stats)", rc);
@@ -289,6 +305,10 @@ int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, i
         printf("batch %s: agents %lld episodes %d converged %lld env-steps %lld mean-rules %.3f mean-reward %.6f (min %.6f max %.6f)\n", env,
                (long long)st.agents, episodes, (long long)st.converged, (long long)st.total_env_steps, st.rules_sum / st.agents,
                st.reward_sum / st.agents, st.reward_min, st.reward_max);
+    if (save_bin) {                               /* all agents' rule bases, before any reduction */
+        rc = frirl_hip_batch_save_rulebases(b, save_bin);
+        if (rc) five_dropin_fatal("frirl_demo_batch_run(save)", rc);
+    }
     if (reduce_strategy == 1 || reduce_strategy == 2) {
         frirl_hip_reduce_result rr;
         rc = frirl_hip_batch_reduce(b, 0, reduce_strategy, 0.0, 0, &rr);

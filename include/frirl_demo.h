@@ -22,5 +22,10 @@ int frirl_demo_batch_run(const char *env, int agents, int max_episodes, const ch
 /* the same, followed by the rule-base reduction (strategy 1 | 2, frirl_sequential_run.c:170-350) of agent 0's rule base on the
  * GPU (frirl_hip_batch_reduce); out_txt then holds the REDUCED rule base.  reduce_strategy 0 = frirl_demo_batch_run. */
 int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, int reduce_strategy, const char *out_txt, int verbose);
+/* the same; load_bin != NULL: instead of learning, every agent gets a rule base from that .frirlrb.bin file (written by the
+ * reference, by the drop-in library or by frirl_hip_batch_save_rulebases) and replays one greedy episode on it
+ * (frirl_test_run), then the optional reduction */
+int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int reduce_strategy, const char *load_bin, const char *save_bin,
+                            const char *out_txt, int verbose);   /* save_bin != NULL: all agents' rule bases (before the reduction) go there */
 
 #endif

@@ -403,6 +403,16 @@ int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *epi
 int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out);
 /* rule base of agent e: *R rules, rant HOST [>= *R][nant] (AoS), rconc HOST [>= *R] (pass NULL to query *R only) */
 int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32_t *R, double *rant, double *rconc);
+/* Rule bases of all agents to / from one file.  The file is E records back to back, each exactly what
+ * frirl_save_rb_to_bin_file writes for one agent (reference src/frirl/frirl_utils.c:151-205): int32 numofrules, then per
+ * rule nant raw antecedents + the consequent as doubles -- so a file saved by the reference (or by the drop-in library) is
+ * a valid one-record file, and the first record of a batch file loads in the reference.  Loading re-adds every rule
+ * through FIVE_add_rule's snap (as frirl_load_rb_from_bin_file does, :237-281), clears fus_is_rule_inserted and the
+ * convergence state; a file with fewer than E records gives the remaining agents a copy of its LAST record (one trained
+ * rule base for every agent).  Unlike the reference's loader it is bounds-checked: a truncated file, a rule count outside
+ * 1..maxR or a non-finite value fails with FRIRL_HIP_EINVAL and leaves the batch untouched. */
+int frirl_hip_batch_save_rulebases(frirl_hip_batch *b, const char *path);
+int frirl_hip_batch_load_rulebases(frirl_hip_batch *b, const char *path, int32_t *records_read);
 /* frirl_sequential_run's reduction phase (frirl_sequential_run.c:170-350) for agent e's rule base, in place, through
  * frirl_hip_reduce_shared (speculative batched try-remove); the other agents are untouched */
 int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strategy, double reward_tolerance, int depth, frirl_hip_reduce_result *result);

@@ -193,3 +193,72 @@ def test_c_level_batched_reduction(env, strategy, built, tmp_path):
     assert (mine[:, :-1] == np.array(f.rant[: f.R])).all()
     rel = np.abs(mine[:, -1] - f.rconc[: f.R]) / np.maximum(np.abs(f.rconc[: f.R]), 1e-9)
     assert rel.max() <= 1e-6
+
+
+def write_bin(path, records):
+    """.frirlrb.bin records as frirl_save_rb_to_bin_file writes them: int32 R, then R x (nant antecedents + consequent) doubles."""
+    with open(path, "wb") as f:
+        for rant, rconc in records:
+            f.write(np.int32(len(rconc)).tobytes())
+            f.write(np.ascontiguousarray(np.concatenate([rant, rconc[:, None]], axis=1), dtype=np.float64).tobytes())
+
+
+def read_bin(path, nant):
+    raw = open(path, "rb").read()
+    out, off = [], 0
+    while off < len(raw):
+        R = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=off)[0])
+        off += 4
+        a = np.frombuffer(raw, dtype=np.float64, count=R * (nant + 1), offset=off).reshape(R, nant + 1)
+        off += 8 * R * (nant + 1)
+        out.append(a)
+    return out
+
+
+@pytest.mark.gpu
+def test_batched_rulebase_files(built, tmp_path):
+    """rule bases of all agents to / from one file in the reference's .frirlrb.bin record format.
+    (1) `--save` after training: every agent's record equals the oracle's rule base; (2) a one-record file (what the
+    reference writes) loads into every agent, the greedy replay reproduces the oracle's frirl_test_run episode and the
+    reduction its reduced rule base; (3) the multi-record file loads back; (4) the loader is bounds-checked."""
+    from oracle import binding as ob
+    lib, demo = built
+    env, E = "mountaincar", 5
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1
+    f = fr.five
+    R, nant = f.R, f.nant
+    rant, rconc = np.array(f.rant[:R]), np.array(f.rconc[:R])
+    # (1) save
+    r = subprocess.run([demo, "--env", env, "--agents", str(E), "--save", "all.bin"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    recs = read_bin(tmp_path / "all.bin", nant)
+    assert len(recs) == E
+    for a in recs:
+        assert a.shape == (R, nant + 1) and (a[:, :nant] == rant).all()
+        assert (np.abs(a[:, nant] - rconc) <= 1e-9 * np.maximum(np.abs(rconc), 1.0)).all()
+    # (2) one record -> every agent; replay + reduction
+    write_bin(tmp_path / "one.bin", [(rant, rconc)])
+    fr.episode_eval()
+    steps, reward = fr.ep_steps, fr.ep_reward
+    r = subprocess.run([demo, "--env", env, "--agents", str(E), "--load", "one.bin", "--reduce", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "loaded 1 rule base record(s)" in r.stdout
+    assert f"env-steps {E * steps} " in r.stdout and f"mean-rules {R:.3f}" in r.stdout and f"mean-reward {reward:.6f}" in r.stdout, r.stdout
+    fr.reduce(1, 0.0)
+    mine = load_rb(tmp_path / f"{env}.batch.reduced1.frirlrb.txt")
+    assert mine.shape == (f.R, nant + 1) and (mine[:, :-1] == np.array(f.rant[: f.R])).all() and (mine[:, -1] == np.array(f.rconc[: f.R])).all()
+    # (3) the batch file loads back (E records)
+    r = subprocess.run([demo, "--env", env, "--agents", str(E), "--load", "all.bin", "--save", "again.bin"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and f"loaded {E} rule base record(s)" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+    assert open(tmp_path / "again.bin", "rb").read() == open(tmp_path / "all.bin", "rb").read()
+    # (4) bounds checks: truncated record, rule count beyond the capacity, NaN
+    raw = open(tmp_path / "one.bin", "rb").read()
+    open(tmp_path / "trunc.bin", "wb").write(raw[:-12])
+    open(tmp_path / "huge.bin", "wb").write(np.int32(100000).tobytes() + raw[4:])
+    bad = rconc.copy()
+    bad[3] = np.nan
+    write_bin(tmp_path / "nan.bin", [(rant, bad)])
+    for name, msg in (("trunc.bin", "truncated"), ("huge.bin", "capacity"), ("nan.bin", "non-finite")):
+        r = subprocess.run([demo, "--env", env, "--agents", "2", "--load", name], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and msg in (r.stdout + r.stderr), (name, r.stdout[-500:], r.stderr[-500:])
