@@ -223,6 +223,8 @@ def main():
 
         def on_ep(ep, conv):
             lsteps.add_((lenvs.ep_steps.long() * (conv.episodes == ep).long()).sum())
+        if frirl_amd.lib().frirl_hip_lanes_preferred(lprob.nant, lE, lagent.A):
+            frirl_amd.episode_run_lanes(lprob, lagent, lenvs, 0)      # allocates the transposed-rule-base workspace outside the timed region
         sync_all()
         t0 = time.perf_counter()
         conv = frirl_amd.train(lprob, lagent, lenvs, on_episode=on_ep)
@@ -239,6 +241,33 @@ def main():
                      "note": "whole construct run from the 2^nant corner rules (reference: 15548 / 33002 / 21207 steps per agent for "
                              "mountaincar / cartpole / acrobot); rule bases stay small (<= 367 rules): latency / occupancy bound at "
                              "8192 agents, 1.2-1.5e9 env-steps/s at 65536 mountaincar agents (tools/learn_bench.py)"}
+
+    # ---- leg 4: evaluation mode -- greedy roll-outs of many environments on ONE shared, read-only rule base (the one
+    # agent 0 just learned): frirl_test_run's episode, lane group per environment -------------------------------
+    eval_leg = None
+    if learn_leg is not None:
+        ns = lprob.nant - 1
+        dd = frirl_amd.demo_describe(w["env"])
+        one = frirl_amd.Problem(lprob.u, lprob.ve, lprob.rb[0:1].clone(), lprob.nrules[0:1].clone())
+        Qn = 65536
+        g = torch.Generator(device=device)
+        g.manual_seed(7 + rank)
+        lo = torch.tensor([dd["grids"][k].min() for k in range(ns)], dtype=torch.float64, device=device)
+        hi = torch.tensor([dd["grids"][k].max() for k in range(ns)], dtype=torch.float64, device=device)
+        vd = torch.tensor([dd["values_def"][k] for k in range(ns)], dtype=torch.float64, device=device)
+        ss = (vd + (torch.rand((Qn, ns), dtype=torch.float64, device=device, generator=g) - 0.5) * 0.2 * (hi - lo)).clamp(lo, hi).contiguous()
+        one.rollout_shared(lagent, Qn, start_states=ss)
+        sync_all()
+        t0 = time.perf_counter()
+        rsteps, rrew, rsucc, _ = one.rollout_shared(lagent, Qn, start_states=ss)
+        sync_all()
+        edt = D.max_over_ranks(time.perf_counter() - t0, device)
+        et = torch.tensor([float(rsteps.sum().item()), float((rsucc == 1).sum().item())], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(et)
+        eval_leg = {"value": et[0].item() / edt, "unit": "env-steps/s", "environments": Qn * world, "rules": int(one.nrules[0].item()),
+                    "wall_s": edt, "env_steps": et[0].item(), "episodes_succeeded": et[1].item(),
+                    "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates"}
 
     if rank == 0:
         evals = float(E) * R * args.steps * world
@@ -272,6 +301,8 @@ def main():
             out["env_steps"] = env_leg
         if learn_leg:
             out["learning"] = learn_leg
+        if eval_leg:
+            out["evaluation"] = eval_leg
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
             if tr and not args.envs:
