@@ -14,6 +14,10 @@
 //   index store Ti[tile][r][i] + Tq[tile][r][i]  one packed record of nant 16-bit universe indices (8 or 16 B) + the
 //               consequent; VE values are gathered from an LDS copy of the tables (rb[e][k][r] == ve[k][uidx[e][k][r]]
 //               exactly, five_add_rule.c:76-81): 16 (nant <= 4) or 24 B per rule and 2 loads instead of nant+1
+// With few agents the groups alone cannot fill the chip (8 192 agents x 4 lanes = 512 waves on 1024 SIMDs, and a wave's
+// step is a latency chain): H = 2 / 4 lanes then share each conclusion, lane h summing the rules r = h (mod H) in order;
+// the H partial sums are added in slice order and the lowest exact hit wins -- a fixed two-level order instead of the
+// reference's single chain (as the per-environment kernels' trees), chosen only when waves are scarce.
 // frirl_hip_episode_run_lanes imports the canonical slabs, runs, and exports them again (two small transposes per call:
 // only the first nrules[e] rules move).
 #include "sweeps.h"
@@ -246,16 +250,17 @@ struct LanesArgs {
 
 // One wave = 64/G environments.  APL = conclusions per lane: lanes 0..G-2 hold APL actions each ((G-1)*APL >= A), lane
 // G-1 holds Q(s,a).
-template <int NANT, int APL, int G, int WPE, bool IDX>
+template <int NANT, int APL, int G, int H, int WPE, bool IDX>
 __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const LanesArgs la, const frirl_hip_agent ag, const frirl_hip_envs ev, int nsteps)
 {
-    constexpr int NS = NANT - 1, EPW = FRIRL_WAVE / G;
+    constexpr int NS = NANT - 1, GH = G * H, EPW = FRIRL_WAVE / GH;
     using STORE = typename std::conditional<IDX, StoreIdx<NANT>, StoreF64<NANT>>::type;
     extern __shared__ double tab_s[];                          // [NANT][U] VE tables (if lds_ve), then [NANT][U] universes (if lds_u)
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
     __shared__ double ave_s[FRIRL_HIP_MAX_ACTIONS];
     const int U = la.U, maxR = la.maxR;
-    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE, sub = lane % G, il = lane / G, base = lane - sub;
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+    const int gl = lane % GH, sub = gl % G, h = gl / G, il = lane / GH, base = lane - gl;      // group lane = (rule slice h, conclusion slot sub)
     const int tile = blockIdx.x * LN_WPB + wave, e = tile * EPW + il;
     const bool exists = tile < la.tiles && e < la.E;
     if (la.lds_ve) for (int i = threadIdx.x; i < NANT * U; i += LN_BLOCK) tab_s[i] = la.ve[i];
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                 apt[i] = has_q ? ve1[NS] : ave_s[a < ag.A ? a : 0];
                 sv[i] = 0.0; sw[i] = 0.0; hit[i] = FRIRL_HIP_NO_HIT;
             }
-            for_rules<true, NANT>(st, 0, 1, R, [&](int r, const double (&c)[NANT + 1]) {
+            for_rules<true, NANT>(st, h, H, R, [&](int r, const double (&c)[NANT + 1]) {
                 const double d0 = qsel[0] - c[0];
                 double s = d0 * d0;
 #pragma unroll
@@ -338,6 +343,22 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                     }
                 }
             });
+            if (H > 1) {                    // the H rule slices of each conclusion: sums in slice order, lowest exact hit
+#pragma unroll
+                for (int i = 0; i < APL; i++) {
+                    double tv = __shfl(sv[i], base + sub), tw = __shfl(sw[i], base + sub);
+                    unsigned th = (unsigned)__shfl((int)hit[i], base + sub);
+#pragma unroll
+                    for (int hh = 1; hh < H; hh++) {
+                        const double v = __shfl(sv[i], base + hh * G + sub), w = __shfl(sw[i], base + hh * G + sub);
+                        const unsigned x = (unsigned)__shfl((int)hit[i], base + hh * G + sub);
+                        tv = tv + v;
+                        tw = tw + w;
+                        th = x < th ? x : th;
+                    }
+                    sv[i] = tv; sw[i] = tw; hit[i] = th;
+                }
+            }
             double bv = -__builtin_inf();
             int bi = ag.A;
 #pragma unroll
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                         if (R >= maxR) {
                             status = FRIRL_HIP_UPD_FULL;
                         } else {
-                            if (sub == 0) {
+                            if (gl == 0) {
                                 st.append(R, ve3, idx3, rr.v / rr.w + qdiff);
 #pragma unroll
                                 for (int k = 0; k < NANT; k++) {
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                 if (!finished) {
                     const int rules = fus ? R - 1 : R;                                                  // :30-33
                     if (hit1 != FRIRL_HIP_NO_HIT && (ag.skip_rules == 0 || (ag.skip_rules == 1 && (int)hit1 < rules))) {
-                        if (sub == 0) *st.qptr((int)hit1) = qnow + qdiff;                               // :55
+                        if (gl == 0) *st.qptr((int)hit1) = qnow + qdiff;                                // :55
                         status = FRIRL_HIP_UPD_EXACT;
                     } else if (ag.skip_rules == 1 && hit1 != FRIRL_HIP_NO_HIT && (int)hit1 == rules) {
                         status = FRIRL_HIP_UPD_SKIPPED;                                                 // :61-63
@@ -423,7 +444,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                         if (ag.skip_rules == 0) fus = 0;                                                // :70-73
                         const int r_skip = fus ? R - 1 : -1;                                            // :76,124-126
                         const double iws = 1.0 / ws1;
-                        for_rules<false, NANT>(st, sub, G, R, [&](int r, const double (&c)[NANT + 1]) {   // K6 + K7, rules split over the group
+                        for_rules<false, NANT>(st, gl, GH, R, [&](int r, const double (&c)[NANT + 1]) {   // K6 + K7, rules split over the group
                             const double d0 = ve1[0] - c[0];
                             double s = d0 * d0;
 #pragma unroll
@@ -444,7 +465,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
             if (success == 1 || steps >= ag.max_steps) active = false;                                  // :183, :86
         }
     }
-    if (!exists || sub != 0) return;
+    if (!exists || gl != 0) return;
     if (ev.status) ev.status[e] = was_active ? status : FRIRL_HIP_UPD_INACTIVE;
     if (!was_active) return;
 #pragma unroll
@@ -464,30 +485,38 @@ using namespace frirl_host;
 int frirl_check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs, const char *who);
 
 static int lanes_group(int A) { return A <= 3 ? 4 : 8; }
+// rule slices per conclusion: 1 once the groups alone give the chip >= 2048 waves, else 2 or 4
+static int lanes_slices(int E, int A)
+{
+    if (const char *e = getenv("FRIRL_HIP_LANES_SLICES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    const int epw = FRIRL_WAVE / lanes_group(A);
+    const int tiles = (E + epw - 1) / epw;
+    return tiles >= 2048 ? 1 : (tiles >= 1024 ? 2 : 4);
+}
 static int lanes_apl(int A) { const int g = lanes_group(A); const int apl = (A + g - 2) / (g - 1); return apl <= 1 ? 1 : (apl <= 3 ? 3 : 5); }
 
 extern "C" size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A)
 {
     if (nant < 1 || E < 1 || maxR < 1 || A < 1) return 0;
-    const int epw = FRIRL_WAVE / lanes_group(A);
-    const size_t tiles = ((size_t)E + epw - 1) / epw;
-    return tiles * epw * (size_t)(nant + 1) * (size_t)maxR * sizeof(double);     // f64 store; the index store needs less
+    const size_t envs = ((size_t)E + FRIRL_WAVE - 1) / FRIRL_WAVE * FRIRL_WAVE;      // whole tiles for any group size
+    return envs * (size_t)(nant + 1) * (size_t)maxR * sizeof(double);             // f64 store; the index store needs less
 }
 
-// Measured crossover against the per-environment kernels (profiles/r01_learning.md): the lane groups win once they give
-// the chip >= 1024 waves, and always for the 3-antecedent demo (rule bases of <= ~110 rules).
+// Measured against the per-environment kernels (profiles/r01_learning.md): with up to 4 rule slices per conclusion the
+// lane groups win from 8 192 agents on for all three demos (smallest batch measured; 512 groups' tiles = 2048 waves),
+// and for the 3-antecedent demo (rule bases of <= ~110 rules) at any size tried.
 extern "C" int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A)
 {
     if (nant < 1 || E < 1 || A < 1) return 0;
     const int epw = FRIRL_WAVE / lanes_group(A);
-    return ((E + epw - 1) / epw >= 1024 || nant <= 3) ? 1 : 0;
+    return ((E + epw - 1) / epw >= 512 || nant <= 3) ? 1 : 0;
 }
 
-template <int N, int APL, int G, bool IDX>
+template <int N, int APL, int G, int H, bool IDX>
 static void launch_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev, int nsteps,
                          void *T, hipStream_t s)
 {
-    constexpr int EPW = FRIRL_WAVE / G, W = N <= 4 ? 2 : 4;
+    constexpr int EPW = FRIRL_WAVE / (G * H), W = N <= 4 ? 2 : 4;
     frirl::LanesArgs la;
     la.u = t->u; la.ve = t->ve; la.U = t->U; la.T = T; la.rb = b->rb; la.uidx = b->uidx; la.nrules = b->nrules; la.E = b->E; la.maxR = b->maxR;
     la.tiles = (b->E + EPW - 1) / EPW;
@@ -506,9 +535,9 @@ static void launch_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b
     // latency (measured: mountaincar x 65 536 agents 1.25 -> 1.54e9 env-steps/s; the 5-antecedent kernels lose)
     const int blocks = (la.tiles + frirl::LN_WPB - 1) / frirl::LN_WPB;
     int wpe = (la.tiles > 2048 && N <= 3) ? 4 : 2;
-    if (const char *e = getenv("FRIRL_HIP_LANES_WPE")) { const int v = atoi(e); if (v == 2 || v == 3 || v == 4) wpe = v; }
-#define LANES_GO(WPE) hipLaunchKernelGGL((frirl::episode_run_lanes_kernel<N, APL, G, WPE, IDX>), dim3(blocks), dim3(frirl::LN_BLOCK), dyn, s, la, *ag, *ev, nsteps)
-    if (wpe == 4) LANES_GO(4); else if (wpe == 3) LANES_GO(3); else LANES_GO(2);
+    if (const char *e = getenv("FRIRL_HIP_LANES_WPE")) { const int v = atoi(e); if (v == 2 || v == 4) wpe = v; }
+#define LANES_GO(WPE) hipLaunchKernelGGL((frirl::episode_run_lanes_kernel<N, APL, G, H, WPE, IDX>), dim3(blocks), dim3(frirl::LN_BLOCK), dyn, s, la, *ag, *ev, nsteps)
+    if (wpe == 4) LANES_GO(4); else LANES_GO(2);
 #undef LANES_GO
     if (IDX)          // antecedents of appended rules were written through; only the consequents come back
         hipLaunchKernelGGL(frirl::lanes_export_kernel, dim3(la.tiles, 1), dim3(256), 0, s, b->rb, b->nrules, b->E, N + 1, b->maxR, EPW,
@@ -532,15 +561,21 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     // index store when the caller keeps the 16-bit index mirror and the VE tables fit in LDS (48 KiB)
     bool idx = b->uidx != nullptr && sizeof(double) * t->nant * (size_t)t->U <= 48 * 1024 && t->U <= 65536;
     if (const char *e = getenv("FRIRL_HIP_NO_UIDX")) if (atoi(e) == 1) idx = false;
-#define RUN(N, IDX)                                                                               \
-    do {                                                                                          \
-        if (G == 4) launch_lanes<N, 1, 4, IDX>(t, b, agent, envs, nsteps, workspace, s);          \
-        else if (apl == 1) launch_lanes<N, 1, 8, IDX>(t, b, agent, envs, nsteps, workspace, s);   \
-        else if (apl == 3) launch_lanes<N, 3, 8, IDX>(t, b, agent, envs, nsteps, workspace, s);   \
-        else launch_lanes<N, 5, 8, IDX>(t, b, agent, envs, nsteps, workspace, s);                 \
+    const int H = lanes_slices(b->E, agent->A);
+#define RUN2(N, IDX, HH)                                                                              \
+    do {                                                                                              \
+        if (G == 4) launch_lanes<N, 1, 4, HH, IDX>(t, b, agent, envs, nsteps, workspace, s);          \
+        else if (apl == 1) launch_lanes<N, 1, 8, HH, IDX>(t, b, agent, envs, nsteps, workspace, s);   \
+        else if (apl == 3) launch_lanes<N, 3, 8, HH, IDX>(t, b, agent, envs, nsteps, workspace, s);   \
+        else launch_lanes<N, 5, 8, HH, IDX>(t, b, agent, envs, nsteps, workspace, s);                 \
+    } while (0)
+#define RUN(N, IDX)                                                            \
+    do {                                                                       \
+        if (H == 4) RUN2(N, IDX, 4); else if (H == 2) RUN2(N, IDX, 2); else RUN2(N, IDX, 1); \
     } while (0)
     if (t->nant == 3) { if (idx) RUN(3, true); else RUN(3, false); }
     else { if (idx) RUN(5, true); else RUN(5, false); }
 #undef RUN
+#undef RUN2
     return check_launch("frirl_hip_episode_run_lanes");
 }

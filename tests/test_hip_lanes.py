@@ -9,12 +9,15 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["index-store", "f64-store"])
+@pytest.fixture(params=["index-store", "f64-store", "index-store/1-slice", "f64-store/2-slices"])
 def store(request, monkeypatch):
     """Both rule stores of the lane-group kernel: packed 16-bit universe indices + LDS tables (default when the batch keeps
-    the index mirror) and plain f64 columns (FRIRL_HIP_NO_UIDX=1)."""
-    if request.param == "f64-store":
+    the index mirror) and plain f64 columns (FRIRL_HIP_NO_UIDX=1); rule slices per conclusion: the heuristic's choice (4 for
+    these small batches), or forced to 1 (pure sequential sums, the reference's order) / 2."""
+    if request.param.startswith("f64-store"):
         monkeypatch.setenv("FRIRL_HIP_NO_UIDX", "1")
+    if "/" in request.param:
+        monkeypatch.setenv("FRIRL_HIP_LANES_SLICES", request.param.split("/")[1][0])
     return request.param
 
 
@@ -52,8 +55,8 @@ def test_lane_group_training_reaches_the_oracle_rule_base(env, episodes, steps, 
         assert (ui == f.uidx[None, :, :rules]).all(), "index mirror"
 
 
-@pytest.mark.parametrize("env", ["mountaincar", "acrobot", "cartpole"])
-def test_lane_group_steps_equal_step_kernel(env, store):
+@pytest.mark.parametrize("env,explore", [("mountaincar", False), ("acrobot", False), ("cartpole", False), ("acrobot", True), ("cartpole", True)])
+def test_lane_group_steps_equal_step_kernel(env, explore, store):
     """Same start, per-environment start states (different trajectories, ragged episode ends): chunks of lane-group
     steps vs the same number of frirl_hip_episode_step launches -- states, actions, rule counts, status, step counts
     identical; Q within 1e-10."""
@@ -67,8 +70,9 @@ def test_lane_group_steps_equal_step_kernel(env, store):
         vals = torch.from_numpy(d["grids"][k]).to(dev)
         cols.append(vals[torch.randint(0, len(vals), (E,), generator=g, device=dev)])
     start = torch.stack(cols, 1).contiguous()
-    pa, agent, ea = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300)
-    pb, _, eb = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300)
+    kw = dict(epsilon=0.2, no_random=0, seed=1234, env_id_base=77) if explore else {}      # epsilon-greedy: same counter-based streams
+    pa, agent, ea = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300, **kw)
+    pb, _, eb = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300, **kw)
     for episode in range(3):
         frirl_amd.episode_begin(pa, agent, ea)
         frirl_amd.episode_begin(pb, agent, eb)
