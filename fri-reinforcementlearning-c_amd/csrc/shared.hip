@@ -34,10 +34,12 @@ struct SharedTile {
 //   EXCL: rules whose candidate slot s (slot_g[r], 255 = none) has bit s set in `mask` are treated as removed
 //        (same sums and same first-hit ORDER as the compacted rule base: removal keeps the relative rule order,
 //        five_remove_rule.c:29-85).
-template <int NANT, int AMAX, bool GBA, bool EXCL>
+//   H > 1: H lanes (G apart, slice index h) share every conclusion of this lane: lane h takes the rules r = h (mod H); the
+//        partial sums are added in slice order and the lowest exact hit wins (latency form for few environments).
+template <int NANT, int AMAX, bool GBA, bool EXCL, int G = 1, int H = 1>
 __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double *__restrict__ rb, const uint8_t *__restrict__ slot_g, int R,
                                              int maxR, int p, int abeg, int aend, int nchunks, const double *q, bool live, uint32_t mask,
-                                             double *conc, unsigned &hit0, int &bi, double &bvout)
+                                             double *conc, unsigned &hit0, int &bi, double &bvout, int h = 0)
 {
     constexpr int NS = NANT - 1;
     constexpr int ND = GBA ? NS : NANT;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
             __syncthreads();
             if (live && nacc > 0) {
                 // branch-free body (selects on the exact-hit test and on the try-remove mask): straight-line code per rule
-                for (int r = 0; r < n; r++) {
+                for (int r = h; r < n; r += H) {
                     bool valid = true;
                     if (EXCL) { const unsigned sl = tl.slot[r]; valid = !(sl < 32u && ((mask >> sl) & 1u)); }
                     double d0 = q[0] - tl.col[r];
@@ -103,6 +105,24 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                         sh[0] = (z && valid && sh[0] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[0];
                     }
                 }
+            }
+        }
+        if (H > 1 && live) {             // combine the H rule slices (all lanes of an environment are live together)
+            const int lane = threadIdx.x & (FRIRL_WAVE - 1);
+            const int first = lane - h * G;
+#pragma unroll
+            for (int a = 0; a < AMAX; a++) {
+                double tv = __shfl(sv[a], first), tw = __shfl(sw[a], first);
+                unsigned th = (unsigned)__shfl((int)sh[a], first);
+#pragma unroll
+                for (int hh = 1; hh < H; hh++) {
+                    const double v = __shfl(sv[a], first + hh * G), w = __shfl(sw[a], first + hh * G);
+                    const unsigned x = (unsigned)__shfl((int)sh[a], first + hh * G);
+                    tv = tv + v;
+                    tw = tw + w;
+                    th = x < th ? x : th;
+                }
+                sv[a] = tv; sw[a] = tw; sh[a] = th;
             }
         }
         if (live) {
@@ -169,16 +189,16 @@ __device__ __forceinline__ void group_first_max(double &bv, int &bi)
 // rule base stays read-only and can be shared.  G consecutive lanes serve one environment, each evaluating its own
 // block of actions (G = 1 for throughput when Q fills the chip; G = 4 / 8 cut the per-step latency when Q is small, the
 // case of the reduction's replays); the environment state is kept redundantly by all G lanes.
-template <int NANT, int AMAX, int G, bool EXCL>
+template <int NANT, int AMAX, int G, int H, bool EXCL>
 __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                                    const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
                                                                    const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro)
 {
-    constexpr int NS = NANT - 1, EPB = SH_BLOCK / G;
+    constexpr int NS = NANT - 1, GH = G * H, EPB = SH_BLOCK / GH;
     __shared__ SharedTile<NANT> tl;
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
-    const int sub = threadIdx.x % G;
-    const int qi = blockIdx.x * EPB + threadIdx.x / G;
+    const int gl = threadIdx.x % GH, sub = gl % G, h = gl / G;      // group lane = (rule slice h, action slot sub)
+    const int qi = blockIdx.x * EPB + threadIdx.x / GH;
     const bool exists = qi < Q;
     const int R = nrules[0];
     const int p = ag.p > 0 ? ag.p : NANT;
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
     unsigned h0;
     int a;
     double bv;
-    shared_sweep<NANT, AMAX, true, EXCL>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, exists, mask, nullptr, h0, a, bv);   // :78 (un-quantised start state)
+    shared_sweep<NANT, AMAX, true, EXCL, G, H>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, exists, mask, nullptr, h0, a, bv, h);   // :78 (un-quantised start state)
     group_first_max<G>(bv, a);
     a = e_greedy(ag, a, (uint32_t)qi, 0u, 0u);
     double action = grid_s[NS * FRIRL_HIP_MAX_GRID + a];                                                 // :82
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
             for (int k = 0; k < NS; k++) q[k] = observe_ve(u, ve, U, k, qs[k]);
         }
         int pa;
-        shared_sweep<NANT, AMAX, true, EXCL>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, active, mask, nullptr, h0, pa, bv);   // :148
+        shared_sweep<NANT, AMAX, true, EXCL, G, H>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, active, mask, nullptr, h0, pa, bv, h);   // :148
         group_first_max<G>(bv, pa);
         if (active) {
             pa = e_greedy(ag, pa, (uint32_t)qi, 0u, (uint32_t)step);
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
             if (success == 1) active = false;                                                            // :183
         }
     }
-    if (!exists || sub != 0) return;
+    if (!exists || gl != 0) return;
     ro.steps[qi] = steps;
     ro.reward[qi] = total;
     if (ro.success) ro.success[qi] = success;
@@ -289,16 +309,16 @@ extern "C" int frirl_hip_get_best_action_shared(const frirl_hip_tables *t, const
     return check_launch("frirl_hip_get_best_action_shared");
 }
 
-template <int N, int AMAX, int G>
+template <int N, int AMAX, int G, int H>
 static void launch_rollout(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
                            hipStream_t s)
 {
-    constexpr int EPB = frirl::SH_BLOCK / G;
+    constexpr int EPB = frirl::SH_BLOCK / (G * H);
     const dim3 grid((Q + EPB - 1) / EPB);
     if (ro->exclude_mask && ro->rule_slot)
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, true>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, true>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
     else
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, false>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, false>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
 }
 
 // lanes per environment: 1 once the environments alone fill the chip, else split the actions over 4 (A <= 4) or 8 lanes
@@ -309,15 +329,35 @@ static int rollout_group(int Q, int A)
     return A <= 4 ? 4 : 8;
 }
 
+// rule slices per conclusion (G > 1 only): the replays of the reduction run ~1000 environments, one step is then a
+// latency chain over the rules -- 4 or 8 lanes share it while the launch stays under ~2048 waves
+static int rollout_slices(int Q, int G)
+{
+    if (G == 1) return 1;
+    if (const char *e = getenv("FRIRL_HIP_ROLLOUT_SLICES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 8) return v; }
+    const long waves1 = ((long)Q * G + 63) / 64;
+    return waves1 * 8 <= 2048 ? 8 : (waves1 * 4 <= 2048 ? 4 : 1);
+}
+
+template <int N, int AMAX, int G>
+static void launch_rollout_h(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                             hipStream_t s)
+{
+    const int H = rollout_slices(Q, G);
+    if (H == 8) launch_rollout<N, AMAX, G, 8>(t, b, ag, Q, ro, s);
+    else if (H == 4) launch_rollout<N, AMAX, G, 4>(t, b, ag, Q, ro, s);
+    else launch_rollout<N, AMAX, G, 1>(t, b, ag, Q, ro, s);
+}
+
 template <int N>
 static void launch_rollout_n(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
                              hipStream_t s)
 {
     const int G = rollout_group(Q, ag->A);
-    if (G == 4) launch_rollout<N, 1, 4>(t, b, ag, Q, ro, s);
-    else if (G == 8) launch_rollout<N, 4, 8>(t, b, ag, Q, ro, s);
-    else if (ag->A <= 4) launch_rollout<N, 4, 1>(t, b, ag, Q, ro, s);
-    else launch_rollout<N, 8, 1>(t, b, ag, Q, ro, s);
+    if (G == 4) launch_rollout_h<N, 1, 4>(t, b, ag, Q, ro, s);
+    else if (G == 8) launch_rollout_h<N, 4, 8>(t, b, ag, Q, ro, s);
+    else if (ag->A <= 4) launch_rollout<N, 4, 1, 1>(t, b, ag, Q, ro, s);
+    else launch_rollout<N, 8, 1, 1>(t, b, ag, Q, ro, s);
 }
 
 extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, int32_t Q,
