@@ -28,14 +28,13 @@ struct StepShared {
 // frirl_update_sarsa + update_rules (reference src/frirl/frirl_update_sarsa.c:348-385, :22-143).
 // `qp_known`: Q(s',a') already available (fused step: the greedy sweep produced it, identical
 // operands and order -- SURVEY 7(i)); otherwise it is computed by a sweep over ve2.
-template <int NANT, int BLOCK, class COLS>
+template <int NANT, int BLOCK, class COLS, class POW>
 __device__ int update_sarsa_block(const COLS &cols, const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ base,
                                   int maxR, int32_t *nrules_e, const frirl_hip_agent &ag, StepShared &sh, double reward,
                                   bool qp_known, double qp, int32_t *fus_e, double *rant_e, BlockRed<BLOCK> &red,
-                                  const QResult *rn_known = nullptr, uint16_t *uidx_e = nullptr)
+                                  const QResult *rn_known, uint16_t *uidx_e, POW p)
 {
     const int R = *nrules_e;
-    const int p = ag.p > 0 ? ag.p : NANT;
     double q1[NANT], q2[NANT];
 #pragma unroll
     for (int k = 0; k < NANT; k++) { q1[k] = sh.ve1[k]; q2[k] = sh.ve2[k]; }
@@ -135,7 +134,8 @@ __global__ __launch_bounds__(BLOCK) void update_sarsa_kernel(const double *__res
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
     uint16_t *uidx_e = uidx ? uidx + (size_t)e * NANT * maxR : nullptr;
     const auto cols = ColsSel<IDX>::make(base, uidx_e, tab_s, maxR, U);
-    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, reward[e], false, 0.0, ev.fus + e, rant_e, red, nullptr, uidx_e);
+    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, reward[e], false, 0.0, ev.fus + e, rant_e, red, nullptr, uidx_e,
+                                                   ag.p > 0 ? ag.p : NANT);
     if (threadIdx.x == 0 && ev.status) ev.status[e] = st;
 }
 
@@ -187,7 +187,7 @@ __global__ void env_step_kernel(const frirl_hip_agent ag, int E, int ns, const d
 }
 
 // frirl_episode(): start of an episode (reference src/frirl/frirl_episode.c:46-82).
-template <int NANT, int AMAX, int BLOCK, bool IDX>
+template <int NANT, int AMAX, int BLOCK, bool IDX, bool PN>
 __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                                const double *__restrict__ rb, const uint16_t *__restrict__ uidx,
                                                                const int32_t *__restrict__ nrules,
@@ -213,13 +213,14 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
     const double *base = rb + (size_t)e * (NANT + 1) * maxR;
     const double *qcol = base + (size_t)NANT * maxR;
     const auto cols = ColsSel<IDX>::make(base, uidx + (IDX ? (size_t)e * NANT * maxR : 0), tab_s, maxR, U);
+    const auto pw = PowSel<PN, NANT>::make(ag.p > 0 ? ag.p : NANT);
     int a0;
     if (AMAX > 8) {
         __shared__ BlockRed<BLOCK> red;
         double dummy[NANT] = {};
-        a0 = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(cols, qcol, nrules[e], q, dummy, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, nullptr);   // :78
+        a0 = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(cols, qcol, nrules[e], q, dummy, pw, ag.A, gs, red, nullptr);   // :78
     } else {
-        a0 = sweep_gba<NANT, AMAX, BLOCK>(cols, qcol, nrules[e], q, ag.p > 0 ? ag.p : NANT, ag.A, gs);   // :78
+        a0 = sweep_gba<NANT, AMAX, BLOCK>(cols, qcol, nrules[e], q, pw, ag.A, gs);   // :78
     }
     if (threadIdx.x == 0) {
         const uint32_t epi = ev.episode ? (uint32_t)(ev.episode[e] + 1) : 0u;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 }
 
 // frirl_episode(): one step of the loop (reference src/frirl/frirl_episode.c:86-185), fused.
-template <int NANT, int AMAX, int BLOCK, bool IDX>
+template <int NANT, int AMAX, int BLOCK, bool IDX, bool PN>
 __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                               double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules,
                                                               int maxR, const frirl_hip_agent ag, const frirl_hip_envs ev)
@@ -274,10 +275,11 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     double q1[NANT];
 #pragma unroll
     for (int k = 0; k < NANT; k++) q1[k] = sh.ve1[k];
+    const auto pw = PowSel<PN, NANT>::make(ag.p > 0 ? ag.p : NANT);
     QResult rn;
     // one pass over the slab: greedy action for s' (:148) AND Q(s,a) of the pending update (frirl_update_sarsa.c:357)
-    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, &rn)
-                              : sweep_gba_q<NANT, AMAX, BLOCK>(cols, qcol, nrules[e], q, q1, ag.p > 0 ? ag.p : NANT, ag.A, gs, red, rn);
+    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn)
+                              : sweep_gba_q<NANT, AMAX, BLOCK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn);
     if (threadIdx.x == 0) {
         const int chosen = e_greedy(ag, ap, (uint32_t)e, ev.episode ? (uint32_t)ev.episode[e] : 0u, (uint32_t)ev.ep_steps[e] + 1u);
         gs.best = chosen;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__res
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
     int st = FRIRL_HIP_UPD_INACTIVE;
     if (!ag.evaluate)                                                                                 // :155 (reduction_state == 0)
-        st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn, uidx_e);  // :159
+        st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn, uidx_e, pw);  // :159
     if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
     if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.cur_q_ant[threadIdx.x];    // :166-168
     if (threadIdx.x == 0) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
         __syncthreads();
         const double qp = gs.actconc[gs.best];
         int st = FRIRL_HIP_UPD_INACTIVE;
-        if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr);
+        if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr, p);
         __syncthreads();
         if (st == FRIRL_HIP_UPD_INSERTED && rant_e && threadIdx.x < NANT) rant_e[(size_t)threadIdx.x * maxR + (nrules_s - 1)] = sh.rant[threadIdx.x];
         if (st == FRIRL_HIP_UPD_FULL) {                // LDS slab full: hand the (unchanged) step back to the caller
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void mirror_step_kernel(const double *__rest
     if (threadIdx.x < NANT) out->cur_q_ant[threadIdx.x] = sh.cur_q_ant[threadIdx.x];
     const double qp = gs.actconc[ap];
     const int R_before = nrules[0];
-    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, rb, maxR, nrules, ag, sh, in.reward, true, qp, &fus_s, rant_store, red, &rn, nullptr);
+    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, rb, maxR, nrules, ag, sh, in.reward, true, qp, &fus_s, rant_store, red, &rn, nullptr, p);
     __syncthreads();
     const int R = (st == FRIRL_HIP_UPD_INSERTED) ? R_before + 1 : R_before;
     for (int r = threadIdx.x; r < R; r += BLOCK) rconc_out[r] = rb[(size_t)NANT * maxR + r];
@@ -594,19 +596,22 @@ template <int N, int AMAX, int BLOCK, bool BEGIN>
 static void launch_episode_v(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
                              hipStream_t s)
 {
-    const bool idx = BLOCK == 256 && frirl::use_uidx(t, b);      // large rule bases only (use_uidx), never the one-wave variant
+    // compressed index mirror: large rule bases only (use_uidx); with one wave per environment only while the per-workgroup
+    // LDS copy of the VE tables is small (<= 4 KiB: it does not limit the waves per CU)
+    const bool idx = frirl::use_uidx(t, b) && (BLOCK == 256 || sizeof(double) * t->nant * (size_t)t->U <= 4096);
     const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
+    const bool pn = ag->p <= 0 || ag->p == N;                     // the Shepard power is the default nant: straight-line power (PowC<N>)
+#define EP_GO(KERNEL, IDX_, PN_, DYN)                                                                                                            \
+    hipLaunchKernelGGL((frirl::KERNEL<N, AMAX, BLOCK, IDX_, PN_>), dim3(b->E), dim3(BLOCK), DYN, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
+                       b->maxR, *ag, *ev)
     if (BEGIN) {
-        if (idx) hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, BLOCK, true>), dim3(b->E), dim3(BLOCK), tab, s, t->u, t->ve, t->U, b->rb, b->uidx,
-                                    b->nrules, b->maxR, *ag, *ev);
-        else hipLaunchKernelGGL((frirl::episode_begin_kernel<N, AMAX, BLOCK, false>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->uidx,
-                                b->nrules, b->maxR, *ag, *ev);
+        if (idx) { if (pn) EP_GO(episode_begin_kernel, true, true, tab); else EP_GO(episode_begin_kernel, true, false, tab); }
+        else { if (pn) EP_GO(episode_begin_kernel, false, true, 0); else EP_GO(episode_begin_kernel, false, false, 0); }
     } else {
-        if (idx) hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, BLOCK, true>), dim3(b->E), dim3(BLOCK), tab, s, t->u, t->ve, t->U, b->rb, b->uidx,
-                                    b->nrules, b->maxR, *ag, *ev);
-        else hipLaunchKernelGGL((frirl::episode_step_kernel<N, AMAX, BLOCK, false>), dim3(b->E), dim3(BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->uidx,
-                                b->nrules, b->maxR, *ag, *ev);
+        if (idx) { if (pn) EP_GO(episode_step_kernel, true, true, tab); else EP_GO(episode_step_kernel, true, false, tab); }
+        else { if (pn) EP_GO(episode_step_kernel, false, true, 0); else EP_GO(episode_step_kernel, false, false, 0); }
     }
+#undef EP_GO
 }
 
 // Workgroup shape: 256 threads per environment for large rule bases (bandwidth); ONE wave per environment while
@@ -617,7 +622,10 @@ template <int N, bool BEGIN>
 static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
                            hipStream_t s)
 {
-    const bool small = b->maxR <= 2048;
+    // one wave per environment: small rule bases, or mid-size ones when the environments alone fill the chip (>= 4 waves
+    // per SIMD): measured at 8192 rules x 8192 envs 0.320 -> 0.295 ms per step; at 65 536 rules the 256-thread form wins
+    bool small = b->maxR <= 2048 || (b->maxR <= 8192 && b->E >= 4096);
+    if (const char *e = getenv("FRIRL_HIP_STEP_WAVE")) small = atoi(e) == 1 ? true : (atoi(e) == 0 ? false : small);
     if (ag->A <= 4) { if (small) launch_episode_v<N, 4, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 4, 256, BEGIN>(t, b, ag, ev, s); }
     else if (ag->A <= 8) { if (small) launch_episode_v<N, 8, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 8, 256, BEGIN>(t, b, ag, ev, s); }
     else launch_episode_v<N, 32, 256, BEGIN>(t, b, ag, ev, s);            // > 8 actions: action-parallel waves (sweep_gba_wide)

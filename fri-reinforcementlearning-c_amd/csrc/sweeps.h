@@ -55,6 +55,34 @@ __device__ __forceinline__ double inv_dist_pow(double s, int p)
     return w;
 }
 
+// Shepard power as a type: PowC<P> (compile-time, straight-line y^P) or plain int (run-time loop).  Every demo and every
+// BASELINE configuration uses p = nant (FIVEInit.c:89-93), so the hot kernels are instantiated with PowC<NANT>: no scalar
+// loop and no branch per conclusion (the env-step kernel's loop body was ~40 % scalar/branch instructions).
+template <int P>
+struct PowC {};
+
+__device__ __forceinline__ double shepard_w(double s, int p) { return inv_dist_pow<false>(s, p); }
+
+template <int P>
+__device__ __forceinline__ double shepard_w(double s, PowC<P>)
+{
+    double y = __builtin_amdgcn_rsq(s);
+    const double t = s * y;
+    const double e = __fma_rn(-t, y, 1.0);
+    const double c = __fma_rn(0.375, e, 0.5);
+    const double ce = c * e;
+    y = __fma_rn(y, ce, y);
+    double w = y;
+#pragma unroll
+    for (int i = 1; i < P; i++) w = w * y;       // same multiplication order as the run-time loop: bit-identical results
+    return w;
+}
+
+template <bool PN, int N>
+struct PowSel { static __device__ __forceinline__ int make(int p) { return p; } };
+template <int N>
+struct PowSel<true, N> { static __device__ __forceinline__ PowC<N> make(int) { return PowC<N>(); } };
+
 template <int BLOCK>
 struct BlockRed {
     static constexpr int WAVES = BLOCK / FRIRL_WAVE;
@@ -108,6 +136,9 @@ struct ColsF64 {
     const double *base;   // rb slab of the environment
     int maxR;
     __device__ __forceinline__ double2 pair(int k, int r) const { return load_col2(base + (size_t)k * maxR + r); }
+    using raw_t = double2;                 // raw()/decode(): the global load split from its use (software prefetch)
+    __device__ __forceinline__ raw_t raw(int k, int r) const { return pair(k, r); }
+    __device__ __forceinline__ double2 decode(int, const raw_t &w) const { return w; }
 };
 
 struct ColsIdx {
@@ -122,6 +153,15 @@ struct ColsIdx {
         v.y = tab[k * U + (w >> 16)];
         return v;
     }
+    using raw_t = uint32_t;
+    __device__ __forceinline__ raw_t raw(int k, int r) const { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(idx + (size_t)k * maxR + r)); }
+    __device__ __forceinline__ double2 decode(int k, raw_t w) const
+    {
+        double2 v;
+        v.x = tab[k * U + (w & 0xFFFFu)];
+        v.y = tab[k * U + (w >> 16)];
+        return v;
+    }
 };
 
 // rule base resident in LDS (persistent episode kernel): plain 16-byte reads of the workgroup's own slab copy
@@ -129,6 +169,9 @@ struct ColsLds {
     const double *base;   // LDS [nant+1][cap]
     int cap;
     __device__ __forceinline__ double2 pair(int k, int r) const { return *reinterpret_cast<const double2 *>(base + (size_t)k * cap + r); }
+    using raw_t = double2;
+    __device__ __forceinline__ raw_t raw(int k, int r) const { return pair(k, r); }
+    __device__ __forceinline__ double2 decode(int, const raw_t &w) const { return w; }
 };
 
 template <bool IDX>
@@ -182,8 +225,8 @@ struct QResult {
 // FIVE_vag_concl's sweep (reference src/five/FIVEVagConcl.c:64-351 live path): distances, first
 // exact hit, Shepard sums wi = 1/d^p, vagc = sum wi*Q, ws = sum wi (:224-235).  All threads return
 // the same QResult.
-template <int NANT, int BLOCK, class COLS>
-__device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&q)[NANT], int p, BlockRed<BLOCK> &red)
+template <int NANT, int BLOCK, class COLS, class POW>
+__device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&q)[NANT], POW p, BlockRed<BLOCK> &red)
 {
     unsigned best = FRIRL_HIP_NO_HIT;
     double sv = 0.0, sw = 0.0;
@@ -193,7 +236,7 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
         const double2 c = load_col2(qcol + r);
         if (a0 == 0.0) best = min(best, (unsigned)r);
         else {
-            const double wi = inv_dist_pow(a0, p);
+            const double wi = shepard_w(a0, p);
             const double t = wi * c.x;
             sv = sv + t;
             sw = sw + wi;
@@ -201,7 +244,7 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
         if (r + 1 < R) {
             if (a1 == 0.0) best = min(best, (unsigned)(r + 1));
             else {
-                const double wi = inv_dist_pow(a1, p);
+                const double wi = shepard_w(a1, p);
                 const double t = wi * c.y;
                 sv = sv + t;
                 sw = sw + wi;
@@ -218,15 +261,15 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
 // FIVE_vag_concl_weight's second pass (reference src/five/FIVEVagConclWeight.c:125-166, K6):
 // weights[r] = (1/d_r^p) / ws for r < R.  Distances are recomputed (8*nant B/rule re-read) instead
 // of spilling wi[] to HBM and reading it back (16 B/rule).
-template <int NANT, int BLOCK, class COLS>
-__device__ void sweep_weights(const COLS &cols, int R, const double (&q)[NANT], int p, double ws, double *__restrict__ weights)
+template <int NANT, int BLOCK, class COLS, class POW>
+__device__ void sweep_weights(const COLS &cols, int R, const double (&q)[NANT], POW p, double ws, double *__restrict__ weights)
 {
     const double iws = 1.0 / ws;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
         sq_dist2<NANT>(cols, r, q, a0, a1);
-        const double w0 = inv_dist_pow(a0, p) * iws;
-        const double w1 = inv_dist_pow(a1, p) * iws;
+        const double w0 = shepard_w(a0, p) * iws;
+        const double w1 = shepard_w(a1, p) * iws;
         if (r + 1 < R) {
             double2 w; w.x = w0; w.y = w1;
             *reinterpret_cast<double2 *>(weights + r) = w;
@@ -237,16 +280,16 @@ __device__ void sweep_weights(const COLS &cols, int R, const double (&q)[NANT], 
 // update_rules' masked write-back (reference src/frirl/frirl_update_sarsa.c:89-120, K7):
 // rconc[r] = qnow + qdiff * w_r where w_r = wi_r / ws > threshold (strict, ordered compare).
 // `r_skip` (or -1) is left untouched: the just-inserted last rule under skip_rules (:31-33,124-126).
-template <int NANT, int BLOCK, class COLS>
-__device__ void sweep_update(const COLS &cols, double *__restrict__ qcol, int R, const double (&q)[NANT], int p, double ws, double qnow,
+template <int NANT, int BLOCK, class COLS, class POW>
+__device__ void sweep_update(const COLS &cols, double *__restrict__ qcol, int R, const double (&q)[NANT], POW p, double ws, double qnow,
                              double qdiff, double threshold, int r_skip)
 {
     const double iws = 1.0 / ws;
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double a0, a1;
         sq_dist2<NANT>(cols, r, q, a0, a1);
-        const double w0 = inv_dist_pow(a0, p) * iws;
-        const double w1 = inv_dist_pow(a1, p) * iws;
+        const double w0 = shepard_w(a0, p) * iws;
+        const double w1 = shepard_w(a1, p) * iws;
         if (w0 > threshold && r != r_skip) { const double t = qdiff * w0; qcol[r] = qnow + t; }
         if (r + 1 < R && w1 > threshold && r + 1 != r_skip) { const double t = qdiff * w1; qcol[r + 1] = qnow + t; }
     }
@@ -270,8 +313,8 @@ struct GbaScratch {
     int best;
 };
 
-template <int NANT, int AMAX, int BLOCK, class COLS>
-__device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1], int p, int A,
+template <int NANT, int AMAX, int BLOCK, class COLS, class POW>
+__device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1], POW p, int A,
                          GbaScratch<AMAX, BLOCK> &s)
 {
     constexpr int NS = NANT - 1;
@@ -293,7 +336,7 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
                 const double d0 = f0 + s0, d1 = f1 + s1;        // squared distances (K5 without the sqrt)
                 if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
                 else {
-                    const double wi = inv_dist_pow(d0, p);
+                    const double wi = shepard_w(d0, p);
                     const double t = wi * c.x;
                     sv[a] = sv[a] + t;
                     sw[a] = sw[a] + wi;
@@ -301,7 +344,7 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
                 if (second) {
                     if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
                     else {
-                        const double wi = inv_dist_pow(d1, p);
+                        const double wi = shepard_w(d1, p);
                         const double t = wi * c.y;
                         sv[a] = sv[a] + t;
                         sw[a] = sw[a] + wi;
@@ -342,9 +385,9 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
 // (frirl_episode.c:148 -> :159), so one pass over the slab serves both: 8*(nant+1) B per rule and step
 // instead of twice that.  Per-lane accumulation order and the reduction tree are those of the two separate
 // sweeps, so every result is bit-identical to running them one after the other.
-template <int NANT, int AMAX, int BLOCK, class COLS>
+template <int NANT, int AMAX, int BLOCK, class COLS, class POW>
 __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
-                           const double (&q1)[NANT], int p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres)
+                           const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres)
 {
     constexpr int NS = NANT - 1;
     double sv[AMAX], sw[AMAX], av[AMAX];
@@ -353,11 +396,31 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; av[a] = (a < A) ? s.ave[a] : 0.0; }
     unsigned qbest = FRIRL_HIP_NO_HIT;
     double qv = 0.0, qw = 0.0;
+    // software prefetch: the loads of the NEXT pair of rules are issued before the ~100 FP64 instructions of the current
+    // pair, so a wave does not sit on s_waitcnt at the top of every iteration
+    typename COLS::raw_t nraw[NANT];
+    double2 nc = {0.0, 0.0};
+    {
+        const int r0 = 2 * (int)threadIdx.x;
+        if (r0 < R) {
+#pragma unroll
+            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r0);
+            nc = load_col2(qcol + r0);
+        }
+    }
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
+        typename COLS::raw_t raw[NANT];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
+        const double2 c = nc;
+        if (r + 2 * BLOCK < R) {
+#pragma unroll
+            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * BLOCK);
+            nc = load_col2(qcol + r + 2 * BLOCK);
+        }
         double2 v[NANT];
 #pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = cols.pair(k, r);
-        const double2 c = load_col2(qcol + r);
+        for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
         const bool second = (r + 1 < R);
         // (1) Q(s,a): full distance to the pending antecedents
         {
@@ -370,10 +433,10 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 a0 = a0 + t0; a1 = a1 + t1;
             }
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = inv_dist_pow(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
+            else { const double wi = shepard_w(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
             if (second) {
                 if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = inv_dist_pow(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
+                else { const double wi = shepard_w(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
             }
         }
         // (2) greedy sweep for the new state: state part once, then every action
@@ -396,10 +459,10 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 const double f0 = e0 * e0, f1 = e1 * e1;
                 const double d0 = f0 + s0, d1 = f1 + s1;        // squared distances
                 if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
-                else { const double wi = inv_dist_pow(d0, p); const double t = wi * c.x; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
+                else { const double wi = shepard_w(d0, p); const double t = wi * c.x; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
                 if (second) {
                     if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
-                    else { const double wi = inv_dist_pow(d1, p); const double t = wi * c.y; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
+                    else { const double wi = shepard_w(d1, p); const double t = wi * c.y; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
                 }
             }
         }
@@ -441,9 +504,9 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
 // columns almost simultaneously, so HBM still sees each rule once (L1/L2 absorb the repeats) while the
 // register footprint drops to AG accumulator pairs.  The optional Q(s,a) sums of the fused episode step are
 // spread over the waves by iteration.  Sums per action are one wave butterfly (deterministic).
-template <int NANT, int AG, int AMAX, int BLOCK, bool WITH_Q, class COLS>
+template <int NANT, int AG, int AMAX, int BLOCK, bool WITH_Q, class COLS, class POW>
 __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
-                              const double (&q1)[NANT], int p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult *qres)
+                              const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult *qres)
 {
     constexpr int NS = NANT - 1;
     constexpr int WAVES = BLOCK / FRIRL_WAVE;
@@ -475,10 +538,10 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                 a0 = a0 + t0; a1 = a1 + t1;
             }
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = inv_dist_pow(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
+            else { const double wi = shepard_w(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
             if (second) {
                 if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = inv_dist_pow(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
+                else { const double wi = shepard_w(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
             }
         }
         double s0, s1;
@@ -500,10 +563,10 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                 const double f0 = e0 * e0, f1 = e1 * e1;
                 const double d0 = f0 + s0, d1 = f1 + s1;
                 if (d0 == 0.0) sh[j] = min(sh[j], (unsigned)r);
-                else { const double wi = inv_dist_pow(d0, p); const double t = wi * c.x; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
+                else { const double wi = shepard_w(d0, p); const double t = wi * c.x; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
                 if (second) {
                     if (d1 == 0.0) sh[j] = min(sh[j], (unsigned)(r + 1));
-                    else { const double wi = inv_dist_pow(d1, p); const double t = wi * c.y; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
+                    else { const double wi = shepard_w(d1, p); const double t = wi * c.y; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
                 }
             }
         }
