@@ -624,7 +624,7 @@ static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases 
 {
     // one wave per environment: small rule bases, or mid-size ones when the environments alone fill the chip (>= 4 waves
     // per SIMD): measured at 8192 rules x 8192 envs 0.320 -> 0.295 ms per step; at 65 536 rules the 256-thread form wins
-    bool small = b->maxR <= 2048 || (b->maxR <= 8192 && b->E >= 4096);
+    bool small = b->maxR <= 2048 || (b->maxR <= 16384 && b->E >= 4096);
     if (const char *e = getenv("FRIRL_HIP_STEP_WAVE")) small = atoi(e) == 1 ? true : (atoi(e) == 0 ? false : small);
     if (ag->A <= 4) { if (small) launch_episode_v<N, 4, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 4, 256, BEGIN>(t, b, ag, ev, s); }
     else if (ag->A <= 8) { if (small) launch_episode_v<N, 8, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 8, 256, BEGIN>(t, b, ag, ev, s); }
