@@ -298,10 +298,12 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
         episode = ev.episode ? (uint32_t)ev.episode[e] : 0u;
     }
     const bool was_active = active;
+    int last_it = -1;                 // last iteration this environment took part in
 
     for (int it = 0; it < nsteps; it++) {
         if (!__any(active ? 1 : 0)) break;
         if (active) {
+            last_it = it;
             double cur[NS], cur_q[NANT], reward;
             int success;
             env_do_action(ag.env_kind, q_ant[NS], states, cur);                                         // frirl_episode.c:97
@@ -466,7 +468,9 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
         }
     }
     if (!exists || gl != 0) return;
-    if (ev.status) ev.status[e] = was_active ? status : FRIRL_HIP_UPD_INACTIVE;
+    // as nsteps launches of the step kernel would leave it: the update of the LAST of the nsteps steps, INACTIVE for an
+    // environment that had finished before it
+    if (ev.status) ev.status[e] = (was_active && last_it == nsteps - 1) ? status : FRIRL_HIP_UPD_INACTIVE;
     if (!was_active) return;
 #pragma unroll
     for (int k = 0; k < NS; k++) ev.states[(size_t)e * NS + k] = states[k];

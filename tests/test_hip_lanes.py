@@ -55,11 +55,13 @@ def test_lane_group_training_reaches_the_oracle_rule_base(env, episodes, steps, 
         assert (ui == f.uidx[None, :, :rules]).all(), "index mirror"
 
 
-@pytest.mark.parametrize("env,explore", [("mountaincar", False), ("acrobot", False), ("cartpole", False), ("acrobot", True), ("cartpole", True)])
-def test_lane_group_steps_equal_step_kernel(env, explore, store):
+@pytest.mark.parametrize("env,explore,maxR", [("mountaincar", False, 256), ("acrobot", False, 256), ("cartpole", False, 256), ("acrobot", True, 256),
+                                              ("cartpole", True, 256), ("mountaincar", False, 40), ("acrobot", True, 40)])
+def test_lane_group_steps_equal_step_kernel(env, explore, maxR, store):
     """Same start, per-environment start states (different trajectories, ragged episode ends): chunks of lane-group
     steps vs the same number of frirl_hip_episode_step launches -- states, actions, rule counts, status, step counts
-    identical; Q within 1e-10."""
+    identical; Q within 1e-10.  maxR = 40: the rule bases fill up, further insertions are refused (status FULL) the same
+    way by both."""
     import torch
     dev = torch.device("cuda", 0)
     E = 37
@@ -71,8 +73,8 @@ def test_lane_group_steps_equal_step_kernel(env, explore, store):
         cols.append(vals[torch.randint(0, len(vals), (E,), generator=g, device=dev)])
     start = torch.stack(cols, 1).contiguous()
     kw = dict(epsilon=0.2, no_random=0, seed=1234, env_id_base=77) if explore else {}      # epsilon-greedy: same counter-based streams
-    pa, agent, ea = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300, **kw)
-    pb, _, eb = frirl_amd.demo_fresh_batch(env, E, 256, dev, start_states=start, max_steps=300, **kw)
+    pa, agent, ea = frirl_amd.demo_fresh_batch(env, E, maxR, dev, start_states=start, max_steps=300, **kw)
+    pb, _, eb = frirl_amd.demo_fresh_batch(env, E, maxR, dev, start_states=start, max_steps=300, **kw)
     for episode in range(3):
         frirl_amd.episode_begin(pa, agent, ea)
         frirl_amd.episode_begin(pb, agent, eb)
@@ -85,9 +87,12 @@ def test_lane_group_steps_equal_step_kernel(env, explore, store):
             assert (pa.nrules == pb.nrules).all(), (episode, chunk, pa.nrules.tolist(), pb.nrules.tolist())
             assert (ea.states == eb.states).all() and (ea.q_ant == eb.q_ant).all()
             assert (ea.fus == eb.fus).all() and (ea.ep_reward == eb.ep_reward).all()
+            assert (ea.status == eb.status).all(), (episode, chunk, ea.status.tolist(), eb.status.tolist())
             R = int(pa.nrules.max())
             qa, qb = pa.rb[:, pa.nant, :R], pb.rb[:, pb.nant, :R]
             assert ((qa - qb).abs() <= 1e-10 * qb.abs().clamp(min=1.0)).all()
             assert (pa.rb[:, : pa.nant, :R] == pb.rb[:, : pb.nant, :R]).all()
             assert (ea.rant[:, :, :R] == eb.rant[:, :, :R]).all()
         assert (ea.done == 1).all()
+    if maxR < 256:
+        assert int(pa.nrules.max()) == maxR, "the small rule bases were meant to fill up"
