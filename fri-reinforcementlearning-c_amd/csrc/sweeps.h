@@ -522,11 +522,27 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
     unsigned qbest = FRIRL_HIP_NO_HIT;
     double qv = 0.0, qw = 0.0;
     int it = 0;
+    // software prefetch of the next pair of rules (as in sweep_gba_q): 4 waves per SIMD here, every s_waitcnt shows
+    typename COLS::raw_t nraw[NANT];
+    double2 nc = {0.0, 0.0};
+    if (2 * lane < R) {
+#pragma unroll
+        for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, 2 * lane);
+        nc = load_col2(qcol + 2 * lane);
+    }
     for (int r = 2 * lane; r < R; r += 2 * FRIRL_WAVE, it++) {
+        typename COLS::raw_t raw[NANT];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
+        const double2 c = nc;
+        if (r + 2 * FRIRL_WAVE < R) {
+#pragma unroll
+            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * FRIRL_WAVE);
+            nc = load_col2(qcol + r + 2 * FRIRL_WAVE);
+        }
         double2 v[NANT];
 #pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = cols.pair(k, r);
-        const double2 c = load_col2(qcol + r);
+        for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
         const bool second = (r + 1 < R);
         if (WITH_Q && (it % WAVES) == wave) {
             double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
