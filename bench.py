@@ -221,8 +221,16 @@ def main():
         lprob, lagent, lenvs = frirl_amd.demo_fresh_batch(w["env"], lE, 1024, device)
         lsteps = torch.zeros((), dtype=torch.int64, device=device)
 
+        ep_log = []
+
         def on_ep(ep, conv):
             lsteps.add_((lenvs.ep_steps.long() * (conv.episodes == ep).long()).sum())
+            # the reference's per-episode report (frirl_sequential_run.c:74-77) for the whole job: reward statistics only
+            # cross the GPUs -- one tiny all-reduce per episode (RCCL over xGMI; latency-bound, overlaps the next episode)
+            st = torch.stack([lenvs.ep_reward.sum(), lenvs.ep_steps.sum().double(), lprob.nrules.sum().double(), conv.converged.sum().double()])
+            if world > 1:
+                dist.all_reduce(st)
+            ep_log.append(st)
         if frirl_amd.lib().frirl_hip_lanes_preferred(lprob.nant, lE, lagent.A):
             frirl_amd.episode_run_lanes(lprob, lagent, lenvs, 0)      # allocates the transposed-rule-base workspace outside the timed region
         sync_all()
@@ -236,6 +244,8 @@ def main():
         learn_leg = {"value": tot[0].item() / ldt, "unit": "env-steps/s", "agents": lE * world, "wall_s": ldt, "env_steps": tot[0].item(),
                      "agents_converged": tot[1].item(), "episodes_to_converge": int(conv.episodes.max().item()),
                      "mean_final_rules": tot[2].item() / (lE * world),
+                     "per_episode_stats_allreduce": {"episodes": len(ep_log), "last": dict(zip(["reward_sum", "steps_sum", "rules_sum", "converged"],
+                                                                                          [float(v) for v in ep_log[-1].tolist()])) if ep_log else None},
                      "kernel": "episode_run_lanes (lane groups)" if frirl_amd.lib().frirl_hip_lanes_preferred(lprob.nant, lE, lagent.A)
                                else "episode_run / episode_step (one wave per environment)",
                      "note": "whole construct run from the 2^nant corner rules (reference: 15548 / 33002 / 21207 steps per agent for "
