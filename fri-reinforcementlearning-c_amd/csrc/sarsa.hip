@@ -235,8 +235,12 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 }
 
 // frirl_episode(): one step of the loop (reference src/frirl/frirl_episode.c:86-185), fused.
+// register budget of the step kernel: 6 waves per SIMD (<= 80 VGPRs) for the 3-antecedent / <= 4-action shape, 4 (<= 128)
+// for the others -- without the bound the 5-antecedent, many-action variants sit just above 128 and lose a wave
+constexpr int step_min_waves(int nant, int amax) { return (nant <= 3 && amax <= 4) ? 6 : 4; }
+
 template <int NANT, int AMAX, int BLOCK, bool IDX, bool PN>
-__global__ __launch_bounds__(BLOCK) void episode_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+__global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                               double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules,
                                                               int maxR, const frirl_hip_agent ag, const frirl_hip_envs ev)
 {
