@@ -440,16 +440,17 @@ extern "C" int frirl_hip_reduce_shared(const frirl_hip_tables *t, const frirl_hi
     frirl_hip_rollout ro = {};
     ro.steps = static_cast<int32_t *>(d_steps.p);
     ro.reward = static_cast<double *>(d_reward.p);
-    rc = frirl_hip_rollout_shared(t, b, agent, 1, &ro, stream);
+    frirl_hip_agent greedy = *agent;
+    greedy.no_random = 1;                                             // the replays are greedy (reduction_state == 1 keeps epsilon at 0 in every demo)
+    rc = frirl_hip_rollout_shared(t, b, &greedy, 1, &ro, stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(steps.data(), d_steps.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(reward.data(), d_reward.p, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const int steps_inc = steps[0];
     double prev_reward = reward[0];
-    frirl_hip_agent capped = *agent;
+    frirl_hip_agent capped = greedy;
     if (capped.max_steps > steps_inc + 1) capped.max_steps = steps_inc + 1;
-    capped.no_random = 1;                                             // the replays are greedy (reduction_state == 1 keeps epsilon at 0 in every demo)
 
     std::vector<int> alive(R0);                                       // original index of the rule in each current slot
     std::iota(alive.begin(), alive.end(), 0);
