@@ -262,3 +262,13 @@ def test_batched_rulebase_files(built, tmp_path):
     for name, msg in (("trunc.bin", "truncated"), ("huge.bin", "capacity"), ("nan.bin", "non-finite")):
         r = subprocess.run([demo, "--env", env, "--agents", "2", "--load", name], cwd=tmp_path, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and msg in (r.stdout + r.stderr), (name, r.stdout[-500:], r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_demo_parity_script(built):
+    """tests/demo_parity.sh: the non-interactive counterpart of the reference's tests/test_ALL.sh (three demos through the
+    drop-in C API against the golden rule bases of the reference compiled in the build container)."""
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "demo_parity.sh")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for env in ("mountaincar", "cartpole", "acrobot"):
+        assert f"{env}: Valid" in r.stdout, r.stdout
