@@ -54,11 +54,14 @@ def synth_problem(w, device, seed):
         ve[k, 1:] = np.cumsum((u[k, 1:] - u[k, :-1]) * (scf[:-1] + scf[1:]) * 0.5)
     u_d, ve_d = torch.from_numpy(u).to(device), torch.from_numpy(ve).to(device)
     rb = torch.empty((E, nant + 1, R), dtype=torch.float64, device=device)
+    uidx = torch.empty((E, nant, R), dtype=torch.int16, device=device)       # 16-bit universe-index mirror (FIVERB.rseqant_uindex)
     for k in range(nant):
-        rb[:, k, :] = ve_d[k][torch.randint(0, U, (E, R), generator=g, device=device)]
+        ik = torch.randint(0, U, (E, R), generator=g, device=device)
+        rb[:, k, :] = ve_d[k][ik]
+        uidx[:, k, :] = ik.to(torch.int16)
     rb[:, nant, :] = torch.rand((E, R), generator=g, device=device, dtype=torch.float64) * 3000.0 - 1500.0
     nrules = torch.full((E,), R, dtype=torch.int32, device=device)
-    return frirl_amd.Problem(u_d, ve_d, rb, nrules), None, None
+    return frirl_amd.Problem(u_d, ve_d, rb, nrules, uidx), None, None
 
 
 def make_queries(prob, device, seed):
@@ -283,7 +286,8 @@ def main():
         evals = float(E) * R * args.steps * world
         alg_bytes = 8.0 * (nant + 1) * E * R                 # SURVEY 8d U1 contract figure (f64 SoA layout): 8*nant read + 8 written per eval
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        compressed = prob.uidx is not None and 8 * nant * w["U"] <= 48 * 1024 and not os.environ.get("FRIRL_HIP_NO_UIDX")
+        tabb = 8 * nant * w["U"]
+        compressed = prob.uidx is not None and (tabb <= 48 * 1024 or (nant > 8 and tabb <= 150 * 1024)) and not os.environ.get("FRIRL_HIP_NO_UIDX")
         moved_bytes = (2.0 * nant + 8.0) * E * R if compressed else alg_bytes     # what the kernel actually streams
         moved = moved_bytes / (kern_ms * 1e-3) / 1e9
         out = {

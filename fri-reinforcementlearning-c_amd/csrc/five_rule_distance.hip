@@ -101,8 +101,8 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_kernel(
 // Compressed-antecedent form: the rule base's 2-byte universe indices are streamed (4 B per lane and column:
 // two rules) and the VE values come from an LDS copy of the vague-environment tables.  Same arithmetic on the
 // same operands as above => bit-identical distances; HBM traffic 2*nant B read (+8 B written) per rule.
-template <int NANT, bool WRITE, int UNROLL>
-__global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_idx_kernel(
+template <int NANT, bool WRITE, int UNROLL, int BLOCK = FRIRL_BLOCK>
+__global__ __launch_bounds__(BLOCK) void rule_distance_idx_kernel(
     const double *__restrict__ u, const double *__restrict__ ve, int U, const uint16_t *__restrict__ uidx,
     const int32_t *__restrict__ nrules, int maxR, const double *__restrict__ x, double *__restrict__ dists,
     uint32_t *__restrict__ hit, int rules_per_block)
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_idx_kernel(
     if (r_end > R) r_end = R;
 
     __shared__ double q_s[NANT];
-    __shared__ unsigned red_s[FRIRL_WAVES_PER_BLOCK];
-    for (int i = threadIdx.x; i < NANT * U; i += FRIRL_BLOCK) tab_s[i] = ve[i];
+    __shared__ unsigned red_s[BLOCK / FRIRL_WAVE];
+    for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x < NANT) q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, x[(size_t)e * NANT + threadIdx.x]);
     __syncthreads();
     double q[NANT];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_idx_kernel(
     const uint16_t *__restrict__ base = uidx + (size_t)e * NANT * maxR;
     double *__restrict__ out = WRITE ? dists + (size_t)e * maxR : nullptr;
     unsigned best = FRIRL_HIP_NO_HIT;
-    constexpr int STEP = FRIRL_BLOCK * 2;
+    constexpr int STEP = BLOCK * 2;
 
     for (int r = r0 + 2 * (int)threadIdx.x; r < r_end; r += STEP * UNROLL) {
         uint32_t w[UNROLL][NANT];
@@ -162,8 +162,14 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_idx_kernel(
             }
         }
     }
-    best = block_min_u32(best, red_s);
-    if (threadIdx.x == 0 && best != FRIRL_HIP_NO_HIT) atomicMin(&hit[e], best);
+    best = wave_min_u32(best);
+    if ((threadIdx.x & (FRIRL_WAVE - 1)) == 0) red_s[threadIdx.x / FRIRL_WAVE] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = red_s[0];
+        for (int w = 1; w < BLOCK / FRIRL_WAVE; w++) m = red_s[w] < m ? red_s[w] : m;
+        if (m != FRIRL_HIP_NO_HIT) atomicMin(&hit[e], m);
+    }
 }
 
 struct RdTune { int unroll, chunk, nt; };
@@ -221,6 +227,26 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
         else VI(UI);
 #undef VI
         return frirl_host::check_launch("five_hip_rule_distance(uidx)");
+    }
+    // Large tables (cfg5: 16 x 1001 doubles = 125 KiB): still one LDS copy per workgroup -- gfx950 has 160 KiB of LDS per CU
+    // -- with 1024 threads per workgroup (16 waves per CU on one table) and long rule chunks that amortise the table fill.
+    if (NANT > 8 && b->uidx && t->U <= 65536 && tab_bytes <= 150 * 1024 && !getenv("FRIRL_HIP_NO_UIDX")) {
+        constexpr int BIG = 1024;
+        int rpb = 32768;                                       // rules per workgroup: 16 sweeps of 2048
+        if (rpb > b->maxR) rpb = ((b->maxR + 2 * BIG - 1) / (2 * BIG)) * (2 * BIG);
+        const dim3 g2(b->E, (b->maxR + rpb - 1) / rpb);
+        hipError_t e1;
+        if (ruledists) {
+            auto k = rule_distance_idx_kernel<NANT, true, 2, BIG>;
+            e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes);
+            if (e1 == hipSuccess) hipLaunchKernelGGL(k, g2, dim3(BIG), tab_bytes, s, t->u, t->ve, t->U, b->uidx, b->nrules, b->maxR, x, ruledists, hit, rpb);
+        } else {
+            auto k = rule_distance_idx_kernel<NANT, false, 2, BIG>;
+            e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes);
+            if (e1 == hipSuccess) hipLaunchKernelGGL(k, g2, dim3(BIG), tab_bytes, s, t->u, t->ve, t->U, b->uidx, b->nrules, b->maxR, x, ruledists, hit, rpb);
+        }
+        if (e1 != hipSuccess) { frirl_host::set_error("five_hip_rule_distance: cannot reserve %zu B of LDS: %s", tab_bytes, hipGetErrorString(e1)); return FRIRL_HIP_ELAUNCH; }
+        return frirl_host::check_launch("five_hip_rule_distance(uidx, large tables)");
     }
     const RdTune tn = rd_tune();
     if (NANT <= 5 && (tn.unroll || tn.nt >= 0)) {      // tuning hooks (experiments only)
