@@ -287,7 +287,7 @@ def main():
         alg_bytes = 8.0 * (nant + 1) * E * R                 # SURVEY 8d U1 contract figure (f64 SoA layout): 8*nant read + 8 written per eval
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         tabb = 8 * nant * w["U"]
-        compressed = prob.uidx is not None and (tabb <= 48 * 1024 or (nant > 8 and tabb <= 150 * 1024)) and not os.environ.get("FRIRL_HIP_NO_UIDX")
+        compressed = prob.uidx is not None and tabb <= 150 * 1024 and not os.environ.get("FRIRL_HIP_NO_UIDX")
         moved_bytes = (2.0 * nant + 8.0) * E * R if compressed else alg_bytes     # what the kernel actually streams
         moved = moved_bytes / (kern_ms * 1e-3) / 1e9
         out = {

@@ -230,7 +230,7 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
     }
     // Large tables (cfg5: 16 x 1001 doubles = 125 KiB): still one LDS copy per workgroup -- gfx950 has 160 KiB of LDS per CU
     // -- with 1024 threads per workgroup (16 waves per CU on one table) and long rule chunks that amortise the table fill.
-    if (NANT > 8 && b->uidx && t->U <= 65536 && tab_bytes <= 150 * 1024 && !getenv("FRIRL_HIP_NO_UIDX")) {
+    if (b->uidx && t->U <= 65536 && tab_bytes <= 150 * 1024 && !getenv("FRIRL_HIP_NO_UIDX")) {
         constexpr int BIG = 1024;
         int rpb = 32768;                                       // rules per workgroup: 16 sweeps of 2048
         if (rpb > b->maxR) rpb = ((b->maxR + 2 * BIG - 1) / (2 * BIG)) * (2 * BIG);

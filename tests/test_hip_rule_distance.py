@@ -31,6 +31,7 @@ CASES = [  # nant, U, R, E, A
     (8, 101, 4099, 4, 0),      # reference's maximum nant, odd R > one chunk
     (16, 201, 3000, 3, 0),     # cfg5 shape (nant beyond the reference's cap of 8)
     (16, 1001, 70001, 3, 0),   # cfg5 tables (125 KiB: the large-LDS index kernel, 1024 threads), several chunks, odd R
+    (8, 1001, 5000, 3, 0),     # 62.6 KiB of tables: large-LDS kernel for nant <= 8 too
     (1, 41, 40, 3, 0),
     (3, 41, 20000, 2, 0),      # several chunks per environment + atomicMin across workgroups
 ]
@@ -50,7 +51,7 @@ def test_rule_distance_bit_exact(nant, U, R, E, A):
         assert (bits(d[e, :n]) == bits(d_ref[e, :n])).all(), f"env {e}: distances must be bit-identical"
     _, hit2 = run_case(b, x, materialise=False)
     assert (hit2 == hit).all(), "index-only form"
-    if nant * U * 8 <= 48 * 1024 or (nant > 8 and nant * U * 8 <= 150 * 1024):
+    if nant * U * 8 <= 150 * 1024:
         # compressed-antecedent form (16-bit universe indices + LDS tables): the same bits
         dc, hitc = run_case(b, x, compressed=True)
         assert (hitc == hit).all()
