@@ -86,7 +86,8 @@ typedef struct frirl_hip_rulebases {
                                 2-byte mirror is present the scans stream it (2*nant B/rule instead of 8*nant) and
                                 look the VE values up in an LDS copy of the tables -- bit-identical results, a
                                 quarter of the antecedent traffic.  Appends keep it in sync.  Needs U <= 65536 and
-                                nant*U*8 <= 48 KiB; otherwise the f64 columns are streamed. */
+                                nant*U*8 <= 48 KiB (five_hip_rule_distance: <= 150 KiB, one table copy per 1024-thread
+                                workgroup); otherwise the f64 columns are streamed. */
 } frirl_hip_rulebases;
 
 /* ---- runtime ------------------------------------------------------------------------------- */
