@@ -482,7 +482,7 @@ def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=No
     conv = Convergence(problem, problem.rb.device)
     max_steps = agent.desc.max_steps
     if lanes is None:           # lane-group kernel where it is the faster form (many agents / small rule bases)
-        lanes = bool(lib().frirl_hip_lanes_preferred(problem.nant, problem.E, agent.A))
+        lanes = bool(lib().frirl_hip_lanes_preferred(problem.nant, problem.E, agent.A)) and agent.desc.p in (0, problem.nant)
     for ep in range(1, max_episodes):
         episode_begin(problem, agent, envs)
         envs.done.copy_(torch.maximum(envs.done, conv.converged))       # converged agents sit this episode out

@@ -134,7 +134,7 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
     const int chunk = 64;
     int32_t running = 1;
     // many agents / small rule bases: lane-group kernel, the whole episode in one launch (frirl_hip_episode_run_lanes)
-    if (frirl_hip_lanes_preferred(b->nant, b->E, b->agent.A)) {
+    if (frirl_hip_lanes_preferred(b->nant, b->E, b->agent.A) && (b->agent.p <= 0 || b->agent.p == b->nant)) {
         if (!b->d_lanes_ws) {
             b->lanes_ws_bytes = frirl_hip_lanes_workspace_bytes(b->nant, b->E, b->maxR, b->agent.A);
             BCHK(hipMalloc(&b->d_lanes_ws, b->lanes_ws_bytes), "lane-group workspace");

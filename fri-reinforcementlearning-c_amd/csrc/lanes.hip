@@ -230,7 +230,7 @@ __device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const doub
 #pragma unroll
         for (int k = 1; k < NANT; k++) { const double d = q[k] - c[k]; const double t = d * d; s = s + t; }
         if (s == 0.0) { if (o.hit == FRIRL_HIP_NO_HIT) o.hit = (unsigned)r; }
-        else { const double wi = inv_dist_pow<true>(s, p); const double t = wi * c[NANT]; o.v = o.v + t; o.w = o.w + wi; }
+        else { const double wi = shepard_w(s, PowC<NANT>()); const double t = wi * c[NANT]; o.v = o.v + t; o.w = o.w + wi; }
     });
     return o;
 }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
         st.maxR = maxR;
         st.EPW = EPW;
     }
-    const int p = ag.p > 0 ? ag.p : NANT;
+    const int p = NANT;                  // the Shepard power is the default p = nant (checked by the host): compile-time PowC<NANT>
     const bool has_q = (sub == G - 1);
 
     double states[NS], q_ant[NANT], total = 0.0;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                         const double f = ea * ea;
                         const double d2 = f + s;
                         if (d2 == 0.0) { if (hit[i] == FRIRL_HIP_NO_HIT) hit[i] = (unsigned)r; }
-                        else { const double wi = inv_dist_pow<true>(d2, p); const double t = wi * cq; sv[i] = sv[i] + t; sw[i] = sw[i] + wi; }
+                        else { const double wi = shepard_w(d2, PowC<NANT>()); const double t = wi * cq; sv[i] = sv[i] + t; sw[i] = sw[i] + wi; }
                     }
                 }
             });
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                             double s = d0 * d0;
 #pragma unroll
                             for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; const double t = d * d; s = s + t; }
-                            const double w = inv_dist_pow<true>(s, p) * iws;
+                            const double w = shepard_w(s, PowC<NANT>()) * iws;
                             if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; *st.qptr(r) = qnow + t; }
                         });
                         status = FRIRL_HIP_UPD_SPREAD;
@@ -557,6 +557,11 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     int rc = frirl_check_episode(t, b, agent, envs, "frirl_hip_episode_run_lanes");
     if (rc) return rc;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) { set_error("frirl_hip_episode_run_lanes: workspace must be 16-byte aligned"); return FRIRL_HIP_EINVAL; }
+    if (agent->p > 0 && agent->p != t->nant) {
+        set_error("frirl_hip_episode_run_lanes: the lane-group kernels are built for the default Shepard power p = nant (got p=%d, nant=%d); "
+                  "use frirl_hip_episode_steps", agent->p, t->nant);
+        return FRIRL_HIP_EINVAL;
+    }
     if (nsteps < 0 || !workspace) { set_error("frirl_hip_episode_run_lanes: nsteps=%d / workspace=%p", nsteps, workspace); return FRIRL_HIP_EINVAL; }
     const size_t need = frirl_hip_lanes_workspace_bytes(t->nant, b->E, b->maxR, agent->A);
     if (workspace_bytes < need) { set_error("frirl_hip_episode_run_lanes: workspace %zu B < %zu B (frirl_hip_lanes_workspace_bytes)", workspace_bytes, need); return FRIRL_HIP_EINVAL; }

@@ -291,7 +291,8 @@ int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases
  * frirl_hip_episode_steps: finished environments sit out, status[e] = last update).  The rule bases are transposed into
  * `workspace` ([dev], >= frirl_hip_lanes_workspace_bytes) on entry and back on exit.  Decisions (actions, hits,
  * inserted rules) and distances are those of the step kernel; interpolated Q agrees to ~1e-15 (different summation
- * order than the tree of the per-environment kernels, same as the reference's). */
+ * order than the tree of the per-environment kernels, same as the reference's).  Built for the default Shepard power
+ * (agent->p <= 0 or == nant, FIVEInit.c:89-93); any other p is FRIRL_HIP_EINVAL -- use frirl_hip_episode_steps. */
 size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
 /* 1 when the lane-group form is expected to beat the per-environment kernels for this batch shape (measured crossover) */
 int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A);
