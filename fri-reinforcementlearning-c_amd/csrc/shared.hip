@@ -36,9 +36,9 @@ struct SharedTile {
 //        five_remove_rule.c:29-85).
 //   H > 1: H lanes (G apart, slice index h) share every conclusion of this lane: lane h takes the rules r = h (mod H); the
 //        partial sums are added in slice order and the lowest exact hit wins (latency form for few environments).
-template <int NANT, int AMAX, bool GBA, bool EXCL, int G = 1, int H = 1>
+template <int NANT, int AMAX, bool GBA, bool EXCL, int G = 1, int H = 1, class POW = PowU>
 __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double *__restrict__ rb, const uint8_t *__restrict__ slot_g, int R,
-                                             int maxR, int p, int abeg, int aend, int nchunks, const double *q, bool live, uint32_t mask,
+                                             int maxR, POW p, int abeg, int aend, int nchunks, const double *q, bool live, uint32_t mask,
                                              double *conc, unsigned &hit0, int &bi, double &bvout, int h = 0)
 {
     constexpr int NS = NANT - 1;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                                 const double f = e * e;
                                 const double d2 = f + s;
                                 const bool z = d2 == 0.0;
-                                const double wi = (z || !valid) ? 0.0 : inv_dist_pow<true>(d2, p);      // an exact hit adds +0.0
+                                const double wi = (z || !valid) ? 0.0 : shepard_w(d2, p);      // an exact hit adds +0.0
                                 const double t = wi * cq;
                                 sv[a] = sv[a] + t;
                                 sw[a] = sw[a] + wi;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                         }
                     } else {
                         const bool z = s == 0.0;
-                        const double wi = (z || !valid) ? 0.0 : inv_dist_pow<true>(s, p);
+                        const double wi = (z || !valid) ? 0.0 : shepard_w(s, p);
                         const double t = wi * cq;
                         sv[0] = sv[0] + t;
                         sw[0] = sw[0] + wi;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(SH_BLOCK) void shared_q_kernel(const double *__rest
     unsigned h0;
     int bi;
     double bv;
-    shared_sweep<NANT, AMAX, GBA, false>(tl, rb, nullptr, nrules[0], maxR, p, 0, A, GBA ? (A + AMAX - 1) / AMAX : 1, q, live, 0u,
+    shared_sweep<NANT, AMAX, GBA, false>(tl, rb, nullptr, nrules[0], maxR, PowU{p}, 0, A, GBA ? (A + AMAX - 1) / AMAX : 1, q, live, 0u,
                                          live ? conc + (size_t)qi * (GBA ? A : 1) : nullptr, h0, bi, bv);
     if (!live) return;
     if (GBA) best[qi] = bi;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
     const int qi = blockIdx.x * EPB + threadIdx.x / GH;
     const bool exists = qi < Q;
     const int R = nrules[0];
-    const int p = ag.p > 0 ? ag.p : NANT;
+    const PowC<NANT> p;                                              // default Shepard power p = nant (checked by the host)
     const int apl = (ag.A + G - 1) / G;                              // actions per lane
     const int abeg = (sub * apl < ag.A) ? sub * apl : ag.A;
     const int aend = (abeg + apl < ag.A) ? abeg + apl : ag.A;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
     unsigned h0;
     int a;
     double bv;
-    shared_sweep<NANT, AMAX, true, EXCL, G, H>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, exists, mask, nullptr, h0, a, bv, h);   // :78 (un-quantised start state)
+    shared_sweep<NANT, AMAX, true, EXCL, G, H, PowC<NANT>>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, exists, mask, nullptr, h0, a, bv, h);   // :78 (un-quantised start state)
     group_first_max<G>(bv, a);
     a = e_greedy(ag, a, (uint32_t)qi, 0u, 0u);
     double action = grid_s[NS * FRIRL_HIP_MAX_GRID + a];                                                 // :82
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
             for (int k = 0; k < NS; k++) q[k] = observe_ve(u, ve, U, k, qs[k]);
         }
         int pa;
-        shared_sweep<NANT, AMAX, true, EXCL, G, H>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, active, mask, nullptr, h0, pa, bv, h);   // :148
+        shared_sweep<NANT, AMAX, true, EXCL, G, H, PowC<NANT>>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, active, mask, nullptr, h0, pa, bv, h);   // :148
         group_first_max<G>(bv, pa);
         if (active) {
             pa = e_greedy(ag, pa, (uint32_t)qi, 0u, (uint32_t)step);
@@ -367,6 +367,11 @@ extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_h
     if (rc) return rc;
     if (!agent || !ro || !ro->steps || !ro->reward || !agent->grid_values || !agent->action_ve) { set_error("frirl_hip_rollout_shared: NULL argument"); return FRIRL_HIP_EINVAL; }
     if (agent->A < 1 || agent->A > FRIRL_HIP_MAX_ACTIONS || agent->max_steps < 0) { set_error("frirl_hip_rollout_shared: A=%d / max_steps=%d out of range", agent->A, agent->max_steps); return FRIRL_HIP_EINVAL; }
+    if (agent->p > 0 && agent->p != t->nant) {
+        set_error("frirl_hip_rollout_shared: built for the default Shepard power p = nant (got p=%d, nant=%d); use frirl_hip_episode_steps with "
+                  "agent->evaluate = 1", agent->p, t->nant);
+        return FRIRL_HIP_EINVAL;
+    }
     for (int k = 0; k < t->nant; k++)
         if (agent->grid_len[k] < 1 || agent->grid_len[k] > FRIRL_HIP_MAX_GRID) { set_error("frirl_hip_rollout_shared: grid_len[%d]=%d outside 1..%d", k, agent->grid_len[k], FRIRL_HIP_MAX_GRID); return FRIRL_HIP_EINVAL; }
     if ((ro->exclude_mask == nullptr) != (ro->rule_slot == nullptr)) { set_error("frirl_hip_rollout_shared: exclude_mask and rule_slot go together"); return FRIRL_HIP_EINVAL; }

@@ -78,6 +78,10 @@ __device__ __forceinline__ double shepard_w(double s, PowC<P>)
     return w;
 }
 
+// run-time power with the p = 3 / 5 cases unrolled (low-occupancy kernels)
+struct PowU { int p; };
+__device__ __forceinline__ double shepard_w(double s, PowU r) { return inv_dist_pow<true>(s, r.p); }
+
 template <bool PN, int N>
 struct PowSel { static __device__ __forceinline__ int make(int p) { return p; } };
 template <int N>

@@ -164,7 +164,7 @@ typedef struct frirl_hip_agent {
 
 /* frirl_test_run's greedy roll-out (reference src/frirl/frirl_test_run.c:66-70 -> frirl_episode with reduction_state == 1,
  * frirl_episode.c:28-194 without the update at :155) for Q environments sharing ONE read-only rule base: lane =
- * environment, whole episodes in one launch.  `agent` as for the episode entry points (env_kind, max_steps, grids, action
+ * environment, whole episodes in one launch (default Shepard power only: agent->p <= 0 or == nant).  `agent` as for the episode entry points (env_kind, max_steps, grids, action
  * values / VE points, epsilon-greedy stream keyed by env_id_base + row; alpha/gamma/... unused).
  * Optional "try-remove" view of the rule base (the replays of the rule-base reduction, frirl_sequential_run.c:170-350):
  * rule r carries a candidate slot rule_slot[r] (0..31, 255 = not a candidate); environment q ignores every rule whose
