@@ -250,6 +250,16 @@ def main():
             if world > 1:
                 dist.all_reduce(st)
             ep_log.append(st)
+        # untimed warm-up: one short episode of a 64-agent batch loads the code objects of the episode kernels ...
+        wprob, wagent, wenvs = frirl_amd.demo_fresh_batch(w["env"], 64, 1024, device)
+        frirl_amd.train(wprob, wagent, wenvs, max_episodes=3)
+        del wprob, wagent, wenvs
+        # ... and one pass over the bookkeeping ops (first use of a torch kernel loads its code object: milliseconds each)
+        _w = torch.stack([lenvs.ep_reward.sum(), lenvs.ep_steps.sum().double(), lprob.nrules.sum().double(), torch.zeros((), device=device, dtype=torch.float64)])
+        _w2 = (lenvs.ep_steps.long() * (lprob.nrules == 1).long()).sum()
+        if world > 1:
+            dist.all_reduce(_w)
+        del _w, _w2
         if frirl_amd.lib().frirl_hip_lanes_preferred(lprob.nant, lE, lagent.A):
             frirl_amd.episode_run_lanes(lprob, lagent, lenvs, 0)      # allocates the transposed-rule-base workspace outside the timed region
         sync_all()

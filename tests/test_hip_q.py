@@ -192,3 +192,40 @@ def test_shared_rule_base_evaluation(env, episodes):
         if (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
             assert best[i] == bo
     assert hits > 10
+
+
+@pytest.mark.parametrize("nant,U,R,A", [(2, 41, 300, 3), (8, 101, 1500, 5), (9, 33, 700, 21), (4, 1001, 513, 8)])
+def test_shared_rule_base_evaluation_synthetic_shapes(nant, U, R, A):
+    """The shared-base query kernels for every supported antecedent count (2..9), several tiles of rules, ragged last tile,
+    action chunks (A = 21 > 8), 1 in 8 queries an exact hit: hits / first maxima exact, Q <= 1e-12 (sequential sums)."""
+    import torch
+    from oracle import binding as ob
+    f = ob.synth_problem(nant, U, R, A, seed=nant * 1000 + R)
+    maxR = f.maxR + (f.maxR & 1)
+    rb = np.zeros((1, nant + 1, maxR))
+    rb[0, :nant, :R] = f.veval[:, :R]
+    rb[0, nant, :R] = f.rconc[:R]
+    import frirl_amd
+    prob = frirl_amd.Problem(dev(np.array(f.u)), dev(np.array(f.ve)), dev(rb), dev(np.array([R], dtype=np.int32)))
+    Qn, st = 260, 99
+    x = np.zeros((Qn, nant))
+    for i in range(Qn):
+        x[i], st = ob.synth_query(f, st, i)
+    conc, hit = prob.vag_concl_shared(dev(x))
+    # action VE points: A distinct VE values of the last universe
+    ave = np.array(f.ve)[nant - 1, np.linspace(0, U - 1, A).astype(int)].copy()
+    actconc, best = prob.get_best_action_shared(dev(np.ascontiguousarray(x[:, : nant - 1])), dev(ave))
+    torch.cuda.synchronize()
+    conc, hit, actconc, best = conc.cpu().numpy(), hit.cpu().numpy(), actconc.cpu().numpy(), best.cpu().numpy()
+    hits = 0
+    for i in range(Qn):
+        h, c = f.vag_concl(x[i])
+        assert hit[i] == h, (i, hit[i], h)
+        hits += h >= 0
+        assert (conc[i] == c) if h >= 0 else (rel(conc[i], c) <= 1e-12)
+        bo, ac = f.best_action(x[i, : nant - 1], ave)
+        assert rel(actconc[i], ac).max() <= 1e-12
+        srt = np.sort(ac)
+        if len(srt) < 2 or (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
+            assert best[i] == bo
+    assert hits >= Qn // 10
