@@ -56,7 +56,8 @@ def test_lane_group_training_reaches_the_oracle_rule_base(env, episodes, steps, 
 
 
 @pytest.mark.parametrize("env,explore,maxR", [("mountaincar", False, 256), ("acrobot", False, 256), ("cartpole", False, 256), ("acrobot", True, 256),
-                                              ("cartpole", True, 256), ("mountaincar", False, 40), ("acrobot", True, 40)])
+                                              ("cartpole", True, 256), ("mountaincar", False, 40), ("acrobot", True, 40),
+                                              ("mountaincar", "noskip", 256), ("acrobot", "noskip", 256)])
 def test_lane_group_steps_equal_step_kernel(env, explore, maxR, store):
     """Same start, per-environment start states (different trajectories, ragged episode ends): chunks of lane-group
     steps vs the same number of frirl_hip_episode_step launches -- states, actions, rule counts, status, step counts
@@ -72,9 +73,13 @@ def test_lane_group_steps_equal_step_kernel(env, explore, maxR, store):
         vals = torch.from_numpy(d["grids"][k]).to(dev)
         cols.append(vals[torch.randint(0, len(vals), (E,), generator=g, device=dev)])
     start = torch.stack(cols, 1).contiguous()
-    kw = dict(epsilon=0.2, no_random=0, seed=1234, env_id_base=77) if explore else {}      # epsilon-greedy: same counter-based streams
+    kw = dict(epsilon=0.2, no_random=0, seed=1234, env_id_base=77) if explore is True else {}      # epsilon-greedy: same counter-based streams
     pa, agent, ea = frirl_amd.demo_fresh_batch(env, E, maxR, dev, start_states=start, max_steps=300, **kw)
     pb, _, eb = frirl_amd.demo_fresh_batch(env, E, maxR, dev, start_states=start, max_steps=300, **kw)
+    if explore == "noskip":     # the other update_rules variant (skip_rules = 0: frirl_update_sarsa.c:70-73) and tighter insertion bounds
+        agent.desc.skip_rules = 0
+        agent.desc.qdiff_pos_boundary *= 0.25
+        agent.desc.qdiff_neg_boundary *= 0.25
     # The two kernels add the Shepard sums in different orders (rule slices vs a tree), so a greedy decision may flip where
     # two actions' Q values agree to ~1e-15; such an environment then follows another trajectory.  Environments are compared
     # exactly, at most 2 of the 37 may take a different branch over the whole run, and a diverged one is re-synchronised
