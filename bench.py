@@ -8,7 +8,10 @@ One "step" = one pass of the hot path over one batch: five_hip_rule_distance ove
 rule bases of R rules each (E*R rule-distance evaluations, distances materialised as the reference's
 five_rule_distance does) -- BASELINE.json's metric "rule-distance evals/sec (rules x envs)".  The second
 half of that metric, env-steps/sec, is measured by a second timed leg (fused do_action + reward +
-quantise + greedy sweep + SARSA update per environment) and reported under "env_steps".
+quantise + greedy sweep + SARSA update per environment) and reported under "env_steps".  Two more legs report
+the learning regime ("learning": E agents learn the demo from the reference's initial rule base to convergence,
+per-episode reward statistics all-reduced) and evaluation mode ("evaluation": greedy roll-outs of 65 536
+environments on one shared rule base); "cpu_baseline" times the genuine reference on the host cores (rank 0, N = 1).
 Default workload = BASELINE.json configs[1]: mountaincar (nant 3, U 41, real tables and dynamics),
 8192 rules x 8192 environments per GPU.  Environments are sharded over ranks by env id with no
 data-path collective (weak scaling); only the per-episode reward statistics are all-reduced (RCCL).
