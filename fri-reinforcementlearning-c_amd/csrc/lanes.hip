@@ -230,7 +230,7 @@ __device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const doub
 #pragma unroll
         for (int k = 1; k < NANT; k++) { const double d = q[k] - c[k]; const double t = d * d; s = s + t; }
         if (s == 0.0) { if (o.hit == FRIRL_HIP_NO_HIT) o.hit = (unsigned)r; }
-        else { const double wi = shepard_w(s, PowC<NANT>()); const double t = wi * c[NANT]; o.v = o.v + t; o.w = o.w + wi; }
+        else { const double wi = shepard_w(s, PowC<NANT>()); o.v = __fma_rn(wi, c[NANT], o.v); o.w = o.w + wi; }
     });
     return o;
 }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                         const double f = ea * ea;
                         const double d2 = f + s;
                         if (d2 == 0.0) { if (hit[i] == FRIRL_HIP_NO_HIT) hit[i] = (unsigned)r; }
-                        else { const double wi = shepard_w(d2, PowC<NANT>()); const double t = wi * cq; sv[i] = sv[i] + t; sw[i] = sw[i] + wi; }
+                        else { const double wi = shepard_w(d2, PowC<NANT>()); sv[i] = __fma_rn(wi, cq, sv[i]); sw[i] = sw[i] + wi; }
                     }
                 }
             });

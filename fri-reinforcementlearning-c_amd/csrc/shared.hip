@@ -90,8 +90,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                                 const double d2 = f + s;
                                 const bool z = d2 == 0.0;
                                 const double wi = (z || !valid) ? 0.0 : shepard_w(d2, p);      // an exact hit adds +0.0
-                                const double t = wi * cq;
-                                sv[a] = sv[a] + t;
+                                sv[a] = __fma_rn(wi, cq, sv[a]);
                                 sw[a] = sw[a] + wi;
                                 sh[a] = (z && valid && sh[a] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[a];
                             }
@@ -99,8 +98,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                     } else {
                         const bool z = s == 0.0;
                         const double wi = (z || !valid) ? 0.0 : shepard_w(s, p);
-                        const double t = wi * cq;
-                        sv[0] = sv[0] + t;
+                        sv[0] = __fma_rn(wi, cq, sv[0]);
                         sw[0] = sw[0] + wi;
                         sh[0] = (z && valid && sh[0] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[0];
                     }

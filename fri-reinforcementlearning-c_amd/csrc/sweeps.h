@@ -55,6 +55,8 @@ __device__ __forceinline__ double inv_dist_pow(double s, int p)
     return w;
 }
 
+// The weighted sums sum wi * Q accumulate with one explicit FMA per term (one rounding instead of two, one instruction
+// instead of two); they are interpolated values (<= 1e-6 contract), never compared bit for bit.
 // Shepard power as a type: PowC<P> (compile-time, straight-line y^P) or plain int (run-time loop).  Every demo and every
 // BASELINE configuration uses p = nant (FIVEInit.c:89-93), so the hot kernels are instantiated with PowC<NANT>: no scalar
 // loop and no branch per conclusion (the env-step kernel's loop body was ~40 % scalar/branch instructions).
@@ -241,16 +243,14 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
         if (a0 == 0.0) best = min(best, (unsigned)r);
         else {
             const double wi = shepard_w(a0, p);
-            const double t = wi * c.x;
-            sv = sv + t;
+            sv = __fma_rn(wi, c.x, sv);
             sw = sw + wi;
         }
         if (r + 1 < R) {
             if (a1 == 0.0) best = min(best, (unsigned)(r + 1));
             else {
                 const double wi = shepard_w(a1, p);
-                const double t = wi * c.y;
-                sv = sv + t;
+                sv = __fma_rn(wi, c.y, sv);
                 sw = sw + wi;
             }
         }
@@ -341,16 +341,14 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
                 if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
                 else {
                     const double wi = shepard_w(d0, p);
-                    const double t = wi * c.x;
-                    sv[a] = sv[a] + t;
+                    sv[a] = __fma_rn(wi, c.x, sv[a]);
                     sw[a] = sw[a] + wi;
                 }
                 if (second) {
                     if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
                     else {
                         const double wi = shepard_w(d1, p);
-                        const double t = wi * c.y;
-                        sv[a] = sv[a] + t;
+                        sv[a] = __fma_rn(wi, c.y, sv[a]);
                         sw[a] = sw[a] + wi;
                     }
                 }
@@ -437,10 +435,10 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 a0 = a0 + t0; a1 = a1 + t1;
             }
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = shepard_w(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
+            else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
             if (second) {
                 if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = shepard_w(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
+                else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; }
             }
         }
         // (2) greedy sweep for the new state: state part once, then every action
@@ -463,10 +461,10 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 const double f0 = e0 * e0, f1 = e1 * e1;
                 const double d0 = f0 + s0, d1 = f1 + s1;        // squared distances
                 if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
-                else { const double wi = shepard_w(d0, p); const double t = wi * c.x; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
+                else { const double wi = shepard_w(d0, p); sv[a] = __fma_rn(wi, c.x, sv[a]); sw[a] = sw[a] + wi; }
                 if (second) {
                     if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
-                    else { const double wi = shepard_w(d1, p); const double t = wi * c.y; sv[a] = sv[a] + t; sw[a] = sw[a] + wi; }
+                    else { const double wi = shepard_w(d1, p); sv[a] = __fma_rn(wi, c.y, sv[a]); sw[a] = sw[a] + wi; }
                 }
             }
         }
@@ -558,10 +556,10 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                 a0 = a0 + t0; a1 = a1 + t1;
             }
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = shepard_w(a0, p); const double t = wi * c.x; qv = qv + t; qw = qw + wi; }
+            else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
             if (second) {
                 if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = shepard_w(a1, p); const double t = wi * c.y; qv = qv + t; qw = qw + wi; }
+                else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; }
             }
         }
         double s0, s1;
@@ -583,10 +581,10 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                 const double f0 = e0 * e0, f1 = e1 * e1;
                 const double d0 = f0 + s0, d1 = f1 + s1;
                 if (d0 == 0.0) sh[j] = min(sh[j], (unsigned)r);
-                else { const double wi = shepard_w(d0, p); const double t = wi * c.x; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
+                else { const double wi = shepard_w(d0, p); sv[j] = __fma_rn(wi, c.x, sv[j]); sw[j] = sw[j] + wi; }
                 if (second) {
                     if (d1 == 0.0) sh[j] = min(sh[j], (unsigned)(r + 1));
-                    else { const double wi = shepard_w(d1, p); const double t = wi * c.y; sv[j] = sv[j] + t; sw[j] = sw[j] + wi; }
+                    else { const double wi = shepard_w(d1, p); sv[j] = __fma_rn(wi, c.y, sv[j]); sw[j] = sw[j] + wi; }
                 }
             }
         }
