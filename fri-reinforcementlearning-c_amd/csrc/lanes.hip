@@ -228,7 +228,7 @@ __device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const doub
         const double d0 = q[0] - c[0];
         double s = d0 * d0;
 #pragma unroll
-        for (int k = 1; k < NANT; k++) { const double d = q[k] - c[k]; const double t = d * d; s = s + t; }
+        for (int k = 1; k < NANT; k++) { const double d = q[k] - c[k]; s = __fma_rn(d, d, s); }
         if (s == 0.0) { if (o.hit == FRIRL_HIP_NO_HIT) o.hit = (unsigned)r; }
         else { const double wi = shepard_w(s, PowC<NANT>()); o.v = __fma_rn(wi, c[NANT], o.v); o.w = o.w + wi; }
     });
@@ -332,14 +332,13 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                 const double d0 = qsel[0] - c[0];
                 double s = d0 * d0;
 #pragma unroll
-                for (int k = 1; k < NS; k++) { const double d = qsel[k] - c[k]; const double t = d * d; s = s + t; }
+                for (int k = 1; k < NS; k++) { const double d = qsel[k] - c[k]; s = __fma_rn(d, d, s); }
                 const double va = c[NS], cq = c[NANT];
 #pragma unroll
                 for (int i = 0; i < APL; i++) {
                     if (i < nacc) {
                         const double ea = apt[i] - va;
-                        const double f = ea * ea;
-                        const double d2 = f + s;
+                        const double d2 = __fma_rn(ea, ea, s);
                         if (d2 == 0.0) { if (hit[i] == FRIRL_HIP_NO_HIT) hit[i] = (unsigned)r; }
                         else { const double wi = shepard_w(d2, PowC<NANT>()); sv[i] = __fma_rn(wi, cq, sv[i]); sw[i] = sw[i] + wi; }
                     }
@@ -450,7 +449,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                             const double d0 = ve1[0] - c[0];
                             double s = d0 * d0;
 #pragma unroll
-                            for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; const double t = d * d; s = s + t; }
+                            for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; s = __fma_rn(d, d, s); }
                             const double w = shepard_w(s, PowC<NANT>()) * iws;
                             if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; *st.qptr(r) = qnow + t; }
                         });

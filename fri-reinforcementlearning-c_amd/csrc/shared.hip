@@ -78,7 +78,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                     double d0 = q[0] - tl.col[r];
                     double s = d0 * d0;
 #pragma unroll
-                    for (int k = 1; k < ND; k++) { const double d = q[k] - tl.col[k * SH_TILE + r]; const double t = d * d; s = s + t; }
+                    for (int k = 1; k < ND; k++) { const double d = q[k] - tl.col[k * SH_TILE + r]; s = __fma_rn(d, d, s); }
                     const double cq = tl.col[NANT * SH_TILE + r];
                     if (GBA) {
                         const double va = tl.col[NS * SH_TILE + r];
@@ -86,8 +86,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                         for (int a = 0; a < AMAX; a++) {
                             if (a < nacc) {
                                 const double e = tl.ave[a0 + a] - va;
-                                const double f = e * e;
-                                const double d2 = f + s;
+                                const double d2 = __fma_rn(e, e, s);
                                 const bool z = d2 == 0.0;
                                 const double wi = (z || !valid) ? 0.0 : shepard_w(d2, p);      // an exact hit adds +0.0
                                 sv[a] = __fma_rn(wi, cq, sv[a]);

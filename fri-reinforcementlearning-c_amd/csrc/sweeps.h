@@ -216,9 +216,8 @@ __device__ __forceinline__ void sq_dist2(const COLS &cols, int r, const double (
     for (int k = 1; k < NDIM; k++) {
         d0 = q[k] - v[k].x;
         d1 = q[k] - v[k].y;
-        const double s0 = d0 * d0, s1 = d1 * d1;
-        a0 = a0 + s0;
-        a1 = a1 + s1;
+        a0 = __fma_rn(d0, d0, a0);      // Q sweeps only: the materialised distances (five_rule_distance.hip) keep separate mul / add
+        a1 = __fma_rn(d1, d1, a1);
     }
 }
 
@@ -336,8 +335,7 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
         for (int a = 0; a < AMAX; a++) {
             if (a < A) {
                 const double e0 = av[a] - va.x, e1 = av[a] - va.y;
-                const double f0 = e0 * e0, f1 = e1 * e1;
-                const double d0 = f0 + s0, d1 = f1 + s1;        // squared distances (K5 without the sqrt)
+                const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);        // squared distances (K5 without the sqrt)
                 if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
                 else {
                     const double wi = shepard_w(d0, p);
@@ -431,8 +429,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
 #pragma unroll
             for (int k = 1; k < NANT; k++) {
                 d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
-                const double t0 = d0 * d0, t1 = d1 * d1;
-                a0 = a0 + t0; a1 = a1 + t1;
+                a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
             else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
@@ -449,8 +446,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
 #pragma unroll
             for (int k = 1; k < NS; k++) {
                 d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
-                const double t0 = d0 * d0, t1 = d1 * d1;
-                s0 = s0 + t0; s1 = s1 + t1;
+                s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
             }
         }
         const double2 va = v[NS];
@@ -458,8 +454,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
         for (int a = 0; a < AMAX; a++) {
             if (a < A) {
                 const double e0 = av[a] - va.x, e1 = av[a] - va.y;
-                const double f0 = e0 * e0, f1 = e1 * e1;
-                const double d0 = f0 + s0, d1 = f1 + s1;        // squared distances
+                const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);        // squared distances
                 if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
                 else { const double wi = shepard_w(d0, p); sv[a] = __fma_rn(wi, c.x, sv[a]); sw[a] = sw[a] + wi; }
                 if (second) {
@@ -552,8 +547,7 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
 #pragma unroll
             for (int k = 1; k < NANT; k++) {
                 d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
-                const double t0 = d0 * d0, t1 = d1 * d1;
-                a0 = a0 + t0; a1 = a1 + t1;
+                a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
             else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
@@ -569,8 +563,7 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
 #pragma unroll
             for (int k = 1; k < NS; k++) {
                 d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
-                const double t0 = d0 * d0, t1 = d1 * d1;
-                s0 = s0 + t0; s1 = s1 + t1;
+                s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
             }
         }
         const double2 va = v[NS];
@@ -578,8 +571,7 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
         for (int j = 0; j < AG; j++) {
             if (j < na) {
                 const double e0 = av[j] - va.x, e1 = av[j] - va.y;
-                const double f0 = e0 * e0, f1 = e1 * e1;
-                const double d0 = f0 + s0, d1 = f1 + s1;
+                const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);
                 if (d0 == 0.0) sh[j] = min(sh[j], (unsigned)r);
                 else { const double wi = shepard_w(d0, p); sv[j] = __fma_rn(wi, c.x, sv[j]); sw[j] = sw[j] + wi; }
                 if (second) {
