@@ -506,13 +506,13 @@ extern "C" size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32
 }
 
 // Measured against the per-environment kernels (profiles/r01_learning.md): with up to 4 rule slices per conclusion the
-// lane groups win from 8 192 agents on for all three demos (smallest batch measured; 512 groups' tiles = 2048 waves),
-// and for the 3-antecedent demo (rule bases of <= ~110 rules) at any size tried.
+// lane groups win from 128 tiles on (acrobot x 4096, cartpole x 1024 agents; below that both forms are latency-bound and
+// within +-25 % of each other), and for the 3-antecedent demo (rule bases of <= ~110 rules) at any size tried.
 extern "C" int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A)
 {
     if (nant < 1 || E < 1 || A < 1) return 0;
     const int epw = FRIRL_WAVE / lanes_group(A);
-    return ((E + epw - 1) / epw >= 512 || nant <= 3) ? 1 : 0;
+    return ((E + epw - 1) / epw >= 128 || nant <= 3) ? 1 : 0;
 }
 
 template <int N, int APL, int G, int H, bool IDX>
