@@ -488,13 +488,13 @@ using namespace frirl_host;
 int frirl_check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs, const char *who);
 
 static int lanes_group(int A) { return A <= 3 ? 4 : 8; }
-// rule slices per conclusion: 1 once the groups alone give the chip >= 2048 waves, else 2 or 4
+// rule slices per conclusion: 1 once the groups alone give the chip >= 2048 waves, else 2, 4 or 8
 static int lanes_slices(int E, int A)
 {
-    if (const char *e = getenv("FRIRL_HIP_LANES_SLICES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    if (const char *e = getenv("FRIRL_HIP_LANES_SLICES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
     const int epw = FRIRL_WAVE / lanes_group(A);
     const int tiles = (E + epw - 1) / epw;
-    return tiles >= 2048 ? 1 : (tiles >= 1024 ? 2 : 4);
+    return tiles >= 2048 ? 1 : (tiles >= 1024 ? 2 : (tiles >= 512 ? 4 : 8));
 }
 static int lanes_apl(int A) { const int g = lanes_group(A); const int apl = (A + g - 2) / (g - 1); return apl <= 1 ? 1 : (apl <= 3 ? 3 : 5); }
 
@@ -505,14 +505,14 @@ extern "C" size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32
     return envs * (size_t)(nant + 1) * (size_t)maxR * sizeof(double);             // f64 store; the index store needs less
 }
 
-// Measured against the per-environment kernels (profiles/r01_learning.md): with up to 4 rule slices per conclusion the
-// lane groups win from 128 tiles on (acrobot x 4096, cartpole x 1024 agents; below that both forms are latency-bound and
-// within +-25 % of each other), and for the 3-antecedent demo (rule bases of <= ~110 rules) at any size tried.
+// Measured against the per-environment kernels (profiles/r01_learning.md): with up to 8 rule slices per conclusion the
+// lane groups win at every batch size tried (96 ... 65 536 agents of the three demos).
 extern "C" int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A)
 {
     if (nant < 1 || E < 1 || A < 1) return 0;
     const int epw = FRIRL_WAVE / lanes_group(A);
-    return ((E + epw - 1) / epw >= 128 || nant <= 3) ? 1 : 0;
+    (void)epw;
+    return 1;
 }
 
 template <int N, int APL, int G, int H, bool IDX>
@@ -579,7 +579,7 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     } while (0)
 #define RUN(N, IDX)                                                            \
     do {                                                                       \
-        if (H == 4) RUN2(N, IDX, 4); else if (H == 2) RUN2(N, IDX, 2); else RUN2(N, IDX, 1); \
+        if (H == 8) RUN2(N, IDX, 8); else if (H == 4) RUN2(N, IDX, 4); else if (H == 2) RUN2(N, IDX, 2); else RUN2(N, IDX, 1); \
     } while (0)
     if (t->nant == 3) { if (idx) RUN(3, true); else RUN(3, false); }
     else { if (idx) RUN(5, true); else RUN(5, false); }

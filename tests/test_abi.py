@@ -97,7 +97,7 @@ def test_shared_and_lane_entry_points_refuse_without_gpu(lib):
         ag.grid_len[k] = 3
     res = frirl_amd.ReduceResult()
     assert lib.frirl_hip_lanes_workspace_bytes(3, 100, 64, 3) == 128 * 4 * 64 * 8          # whole 64-environment tiles, f64 store
-    assert lib.frirl_hip_lanes_preferred(3, 10, 3) == 1 and lib.frirl_hip_lanes_preferred(5, 1024, 3) == 0 and lib.frirl_hip_lanes_preferred(5, 4096, 3) == 1
+    assert lib.frirl_hip_lanes_preferred(3, 10, 3) == 1 and lib.frirl_hip_lanes_preferred(5, 96, 3) == 1 and lib.frirl_hip_lanes_preferred(0, 96, 3) == 0
     if torch.cuda.is_available():
         assert lib.frirl_hip_reduce_shared(C.byref(t), C.byref(b1), C.byref(ag), None, 3, 0.0, 0, None, C.byref(res), None) == -2
         assert lib.frirl_hip_reduce_shared(C.byref(t), C.byref(b1), C.byref(ag), None, 1, 0.0, 13, None, C.byref(res), None) == -2

@@ -9,11 +9,11 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["index-store", "f64-store", "index-store/1-slice", "f64-store/2-slices"])
+@pytest.fixture(params=["index-store", "f64-store", "index-store/1-slice", "f64-store/2-slices", "index-store/4-slices"])
 def store(request, monkeypatch):
     """Both rule stores of the lane-group kernel: packed 16-bit universe indices + LDS tables (default when the batch keeps
-    the index mirror) and plain f64 columns (FRIRL_HIP_NO_UIDX=1); rule slices per conclusion: the heuristic's choice (4 for
-    these small batches), or forced to 1 (pure sequential sums, the reference's order) / 2."""
+    the index mirror) and plain f64 columns (FRIRL_HIP_NO_UIDX=1); rule slices per conclusion: the heuristic's choice (8 for
+    these small batches), or forced to 1 (pure sequential sums, the reference's order) / 2 / 4."""
     if request.param.startswith("f64-store"):
         monkeypatch.setenv("FRIRL_HIP_NO_UIDX", "1")
     if "/" in request.param:
