@@ -287,14 +287,16 @@ int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases
 /* Lane-group form for MANY agents with SMALL rule bases (the demos' learning regime; the reference's frirl_omp_run model
  * of one agent per core, frirl_agent.c:294-325, at GPU width): G = 4 or 8 consecutive lanes own one environment, each
  * lane evaluates its share of the A + 1 conclusions of a step over ALL rules sequentially -- the reference's summation
- * order -- so a step needs no reduction and no barrier; up to nsteps consecutive steps per launch (same contract as
- * frirl_hip_episode_steps: finished environments sit out, status[e] = last update).  The rule bases are transposed into
+ * order -- so a step needs no reduction and no barrier (with few agents, H = 2 / 4 / 8 lanes additionally share every
+ * conclusion: lane h sums the rules r = h mod H, the partial sums are added in slice order); up to nsteps consecutive steps
+ * per launch (same contract as frirl_hip_episode_steps: finished environments sit out, status[e] = update of the last step).  The rule bases are transposed into
  * `workspace` ([dev], >= frirl_hip_lanes_workspace_bytes) on entry and back on exit.  Decisions (actions, hits,
  * inserted rules) and distances are those of the step kernel; interpolated Q agrees to ~1e-15 (different summation
  * order than the tree of the per-environment kernels, same as the reference's).  Built for the default Shepard power
  * (agent->p <= 0 or == nant, FIVEInit.c:89-93); any other p is FRIRL_HIP_EINVAL -- use frirl_hip_episode_steps. */
 size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
-/* 1 when the lane-group form is expected to beat the per-environment kernels for this batch shape (measured crossover) */
+/* 1 when the lane-group form is expected to beat the per-environment kernels for this batch shape: with up to 8 rule
+ * slices it did at every size measured (96 ... 65 536 agents of the three demos), so this is 1 for every valid shape */
 int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A);
 int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                                 const frirl_hip_envs *envs, int32_t nsteps, void *workspace, size_t workspace_bytes, void *stream);
