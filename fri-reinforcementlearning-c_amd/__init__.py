@@ -80,6 +80,10 @@ SIGNATURES = {
     "frirl_hip_last_error": (C.c_char_p, []),
     "frirl_hip_device_count": (C.c_int, []),
     "frirl_hip_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "frirl_hip_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "frirl_hip_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "five_hip_rule_distance_uses_uidx": (C.c_int, [C.c_int32, C.c_int32]),
+    "frirl_hip_step_uses_uidx": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "five_hip_rule_distance": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "five_hip_vag_concl": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "five_hip_vag_concl_weight": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -170,6 +174,14 @@ def lib():
 def check(rc, what=""):
     if rc != 0:
         raise FrirlHipError(f"{what}: rc={rc}: {lib().frirl_hip_last_error().decode()}")
+
+
+def set_option(name, value):
+    """frirl_hip_set_option: experiment / test switch (e.g. "no_uidx", "lanes_slices"); returns the previous value."""
+    old = C.c_int()
+    check(lib().frirl_hip_get_option(name.encode(), C.byref(old)), "frirl_hip_get_option")
+    check(lib().frirl_hip_set_option(name.encode(), int(value)), "frirl_hip_set_option")
+    return old.value
 
 
 def _ptr(t):
@@ -465,11 +477,18 @@ class Convergence:
         self.prev_rconc = torch.zeros((E, maxR), dtype=torch.float64, device=device)
         self.converged = torch.zeros((E,), dtype=torch.int32, device=device)
         self.episodes = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.full = torch.zeros((E,), dtype=torch.bool, device=device)     # agents whose rule base refused an append (capacity)
         self.desc = ConvergenceDesc(self.prev_nrules.data_ptr(), self.prev_steps.data_ptr(), self.prev_reward.data_ptr(),
                                     self.prev_rconc.data_ptr(), self.converged.data_ptr(), self.episodes.data_ptr())
         check(lib().frirl_hip_convergence_init(C.byref(problem.bases), problem.nant, C.byref(self.desc), _stream()), "frirl_hip_convergence_init")
 
+    @property
+    def full_envs(self):
+        """Number of agents that hit FRIRL_HIP_UPD_FULL at least once: their TD updates were dropped from then on."""
+        return int(self.full.sum().item())
+
     def update(self, problem, agent, envs, stream=None):
+        self.full |= (envs.status == UPD_FULL) | (problem.nrules >= problem.maxR)     # an append was (or will be) refused
         check(lib().frirl_hip_convergence_update(C.byref(problem.bases), problem.nant, C.byref(agent.desc), C.byref(envs.desc), C.byref(self.desc),
                                                  _stream(stream)), "frirl_hip_convergence_update")
 
@@ -512,6 +531,10 @@ def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=No
             on_episode(ep, conv)
         if bool((conv.converged != 0).all()):
             break
+    if conv.full_envs:
+        import warnings
+        warnings.warn(f"frirl_amd.train: {conv.full_envs} of {problem.E} rule bases reached their capacity of {problem.maxR} rules: "
+                      "appends were refused (FRIRL_HIP_UPD_FULL) and those TD updates dropped", RuntimeWarning)
     return conv
 
 
@@ -540,7 +563,7 @@ def demo_describe(env):
                 reward_good_above=hp[6], qdiff_final_tolerance=hp[7], max_steps=ms.value)
 
 
-def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None, compressed=True):
+def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None, compressed=True, keep_rant=True):
     """E environments of a demo on `device`, each with a private synthetic rule base of R rules: the 2^nant
     corner rules first (reference frirl_init_rb.c:99-126, Q = 0), then rules on the universe grid (uniform
     indices; action column on the A action values) with Q ~ U(-1500, 1500).
@@ -553,7 +576,7 @@ def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None, compressed=True)
     g = torch.Generator(device=device).manual_seed(0x5EED0000 + seed)
     u_d, ve_d = torch.from_numpy(d["u"]).to(device), torch.from_numpy(d["ve"]).to(device)
     rb = torch.zeros((E, nant + 1, maxR), dtype=torch.float64, device=device)
-    rant = torch.zeros((E, nant, maxR), dtype=torch.float64, device=device)
+    rant = torch.zeros((E, nant, maxR), dtype=torch.float64, device=device) if keep_rant else None     # raw antecedents (rule-base dumps only)
     uidx = torch.zeros((E, nant, maxR), dtype=torch.int16, device=device) if compressed else None
     ncorner = 2 ** nant
     # action universe index of every action value (nearest universe point, as FIVE_add_rule snaps it)
@@ -569,7 +592,8 @@ def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None, compressed=True)
         corner = torch.tensor([lo_i if ((j // divider) % 2) == 0 else hi_i for j in range(ncorner)], device=device)
         idx[:, :ncorner] = corner[None]
         rb[:, k, :R] = ve_d[k][idx]
-        rant[:, k, :R] = u_d[k][idx]
+        if keep_rant:
+            rant[:, k, :R] = u_d[k][idx]
         if compressed:
             uidx[:, k, :R] = idx.to(torch.int16)
         del idx
@@ -577,7 +601,7 @@ def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None, compressed=True)
     nrules = torch.full((E,), R, dtype=torch.int32, device=device)
     prob = Problem(u_d, ve_d, rb, nrules, uidx)
     agent = demo_agent(d, device, max_steps)
-    envs = Envs(prob, device, rant_init=rant)
+    envs = Envs(prob, device, keep_rant=keep_rant, rant_init=rant)
     return prob, agent, envs
 
 

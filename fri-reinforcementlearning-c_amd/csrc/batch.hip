@@ -211,6 +211,7 @@ extern "C" int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t
         if (rew[e] < out->reward_min) out->reward_min = rew[e];
         if (rew[e] > out->reward_max) out->reward_max = rew[e];
         out->converged += cv[e] != 0;
+        out->full_agents += nr[e] >= b->maxR;
         if (eps[e] > out->episodes_max) out->episodes_max = eps[e];
     }
     out->total_env_steps = b->total_env_steps;

@@ -97,4 +97,21 @@ int check_launch(const char *what);       // hipGetLastError -> code
 int check_tables(const frirl_hip_tables *t);
 int check_rulebases(const frirl_hip_tables *t, const frirl_hip_rulebases *b);
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Experiment / test switches (frirl_hip_set_option).  Defaults (0 / -1 = the shipped configuration) are read ONCE from
+// the FRIRL_HIP_* environment variables when the library first needs them, never per launch.
+struct Options {
+    int no_uidx;          // 1: ignore the 16-bit index mirror, stream the f64 columns           (FRIRL_HIP_NO_UIDX)
+    int rd_unroll;        // rule-distance scan: column sets in flight per lane, 0 = shipped     (FRIRL_HIP_RD_UNROLL)
+    int rd_chunk;         // rule-distance scan: rules per workgroup, 0 = shipped                (FRIRL_HIP_RD_CHUNK)
+    int rd_nt;            // rule-distance scan: non-temporal variant, -1 = shipped              (FRIRL_HIP_RD_NT)
+    int rd_persist;       // compressed rule-distance scan: -1 = shipped choice, 0 = one workgroup per chunk, 1 = persistent (FRIRL_HIP_RD_PERSIST)
+    int step_wave;        // episode step: 1 = one wave per environment, 0 = 256 threads, -1 = by shape (FRIRL_HIP_STEP_WAVE)
+    int step_envs;        // episode step: environments per workgroup (wave-per-environment form), 0 = by shape (FRIRL_HIP_STEP_ENVS)
+    int lanes_slices;     // lane groups: rule slices per conclusion, 0 = by shape               (FRIRL_HIP_LANES_SLICES)
+    int lanes_wpe;        // lane groups: waves per SIMD, 0 = by shape                           (FRIRL_HIP_LANES_WPE)
+    int rollout_group;    // shared-base roll-out: lanes per environment, 0 = by shape           (FRIRL_HIP_ROLLOUT_GROUP)
+    int rollout_slices;   // shared-base roll-out: rule slices, 0 = by shape                     (FRIRL_HIP_ROLLOUT_SLICES)
+};
+const Options &opts();
 }  // namespace frirl_host

@@ -175,11 +175,11 @@ __global__ __launch_bounds__(BLOCK) void rule_distance_idx_kernel(
 struct RdTune { int unroll, chunk, nt; };
 static RdTune rd_tune()
 {
+    const frirl_host::Options &o = frirl_host::opts();     // read once from the environment / frirl_hip_set_option, not per launch
     RdTune t;
-    const char *u = getenv("FRIRL_HIP_RD_UNROLL"), *c = getenv("FRIRL_HIP_RD_CHUNK"), *n = getenv("FRIRL_HIP_RD_NT");
-    t.unroll = u ? atoi(u) : 0;      // 0 = shipped default
-    t.chunk = c ? atoi(c) : 0;       // 0 = shipped default
-    t.nt = n ? atoi(n) : -1;         // -1 = shipped default (non-temporal loads and stores)
+    t.unroll = o.rd_unroll;          // 0 = shipped default
+    t.chunk = o.rd_chunk;            // 0 = shipped default
+    t.nt = o.rd_nt;                  // -1 = shipped default (non-temporal loads and stores)
     return t;
 }
 
@@ -209,7 +209,7 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
 {
     constexpr int UNROLL = RdConfig<NANT>::UNROLL;
     const size_t tab_bytes = sizeof(double) * NANT * (size_t)t->U;
-    if (b->uidx && t->U <= 65536 && tab_bytes <= 48 * 1024 && !getenv("FRIRL_HIP_NO_UIDX")) {
+    if (b->uidx && t->U <= 65536 && tab_bytes <= 48 * 1024 && !frirl_host::opts().no_uidx) {
         constexpr int UI = (NANT <= 8) ? 4 : 2;
         const int un = (NANT <= 5 && rd_tune().unroll) ? rd_tune().unroll : UI;      // tuning hook (experiments only)
 #define VI(U_)                                                                                                                               \
@@ -230,7 +230,7 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
     }
     // Large tables (cfg5: 16 x 1001 doubles = 125 KiB): still one LDS copy per workgroup -- gfx950 has 160 KiB of LDS per CU
     // -- with 1024 threads per workgroup (16 waves per CU on one table) and long rule chunks that amortise the table fill.
-    if (b->uidx && t->U <= 65536 && tab_bytes <= 150 * 1024 && !getenv("FRIRL_HIP_NO_UIDX")) {
+    if (b->uidx && t->U <= 65536 && tab_bytes <= 150 * 1024 && !frirl_host::opts().no_uidx) {
         constexpr int BIG = 1024;
         int rpb = 32768;                                       // rules per workgroup: 16 sweeps of 2048
         if (rpb > b->maxR) rpb = ((b->maxR + 2 * BIG - 1) / (2 * BIG)) * (2 * BIG);
@@ -265,6 +265,11 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
 }
 
 }  // namespace frirl
+
+extern "C" int five_hip_rule_distance_uses_uidx(int32_t nant, int32_t U)
+{
+    return nant >= 1 && nant <= FRIRL_HIP_MAX_NANT && U <= 65536 && sizeof(double) * nant * (size_t)U <= 150 * 1024 && !frirl_host::opts().no_uidx;
+}
 
 extern "C" int five_hip_rule_distance(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const double *x,
                                       double *ruledists, uint32_t *hit, void *stream)

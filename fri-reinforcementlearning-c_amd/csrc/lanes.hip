@@ -491,7 +491,7 @@ static int lanes_group(int A) { return A <= 3 ? 4 : 8; }
 // rule slices per conclusion: 1 once the groups alone give the chip >= 2048 waves, else 2, 4 or 8
 static int lanes_slices(int E, int A)
 {
-    if (const char *e = getenv("FRIRL_HIP_LANES_SLICES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
+    { const int v = frirl_host::opts().lanes_slices; if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
     const int epw = FRIRL_WAVE / lanes_group(A);
     const int tiles = (E + epw - 1) / epw;
     return tiles >= 2048 ? 1 : (tiles >= 1024 ? 2 : (tiles >= 512 ? 4 : 8));
@@ -538,7 +538,7 @@ static void launch_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b
     // latency (measured: mountaincar x 65 536 agents 1.25 -> 1.54e9 env-steps/s; the 5-antecedent kernels lose)
     const int blocks = (la.tiles + frirl::LN_WPB - 1) / frirl::LN_WPB;
     int wpe = (la.tiles > 2048 && N <= 3) ? 4 : 2;
-    if (const char *e = getenv("FRIRL_HIP_LANES_WPE")) { const int v = atoi(e); if (v == 2 || v == 4) wpe = v; }
+    { const int v = frirl_host::opts().lanes_wpe; if (v == 2 || v == 4) wpe = v; }
 #define LANES_GO(WPE) hipLaunchKernelGGL((frirl::episode_run_lanes_kernel<N, APL, G, H, WPE, IDX>), dim3(blocks), dim3(frirl::LN_BLOCK), dyn, s, la, *ag, *ev, nsteps)
     if (wpe == 4) LANES_GO(4); else LANES_GO(2);
 #undef LANES_GO
@@ -568,7 +568,7 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     const int G = lanes_group(agent->A), apl = lanes_apl(agent->A);
     // index store when the caller keeps the 16-bit index mirror and the VE tables fit in LDS (48 KiB)
     bool idx = b->uidx != nullptr && sizeof(double) * t->nant * (size_t)t->U <= 48 * 1024 && t->U <= 65536;
-    if (const char *e = getenv("FRIRL_HIP_NO_UIDX")) if (atoi(e) == 1) idx = false;
+    if (frirl_host::opts().no_uidx == 1) idx = false;
     const int H = lanes_slices(b->E, agent->A);
 #define RUN2(N, IDX, HH)                                                                              \
     do {                                                                                              \

@@ -1,7 +1,10 @@
 // runtime.hip -- device discovery, error reporting and argument checks of libfrirl_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "device_common.h"
 
@@ -15,6 +18,40 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+static Options g_opts;
+static std::once_flag g_opts_once;
+struct OptName { const char *name, *env; int Options::*field; int def; };
+static const OptName k_opts[] = {
+    {"no_uidx", "FRIRL_HIP_NO_UIDX", &Options::no_uidx, 0},
+    {"rd_unroll", "FRIRL_HIP_RD_UNROLL", &Options::rd_unroll, 0},
+    {"rd_chunk", "FRIRL_HIP_RD_CHUNK", &Options::rd_chunk, 0},
+    {"rd_nt", "FRIRL_HIP_RD_NT", &Options::rd_nt, -1},
+    {"rd_persist", "FRIRL_HIP_RD_PERSIST", &Options::rd_persist, -1},
+    {"step_wave", "FRIRL_HIP_STEP_WAVE", &Options::step_wave, -1},
+    {"step_envs", "FRIRL_HIP_STEP_ENVS", &Options::step_envs, 0},
+    {"lanes_slices", "FRIRL_HIP_LANES_SLICES", &Options::lanes_slices, 0},
+    {"lanes_wpe", "FRIRL_HIP_LANES_WPE", &Options::lanes_wpe, 0},
+    {"rollout_group", "FRIRL_HIP_ROLLOUT_GROUP", &Options::rollout_group, 0},
+    {"rollout_slices", "FRIRL_HIP_ROLLOUT_SLICES", &Options::rollout_slices, 0},
+};
+static void opts_init()
+{
+    for (const OptName &o : k_opts) {
+        const char *e = getenv(o.env);
+        g_opts.*(o.field) = e ? atoi(e) : o.def;
+    }
+}
+const Options &opts()
+{
+    std::call_once(g_opts_once, opts_init);
+    return g_opts;
+}
+static const OptName *find_opt(const char *name)
+{
+    if (name) for (const OptName &o : k_opts) if (!strcmp(o.name, name)) return &o;
+    return nullptr;
 }
 
 int check_device()
@@ -78,6 +115,23 @@ extern "C" {
 const char *frirl_hip_version(void) { return "frirl-hip 0.1 (gfx950)"; }
 
 const char *frirl_hip_last_error(void) { return frirl_host::g_err; }
+
+int frirl_hip_set_option(const char *name, int value)
+{
+    const frirl_host::OptName *o = frirl_host::find_opt(name);
+    if (!o) { frirl_host::set_error("frirl_hip_set_option: unknown option '%s'", name ? name : "(null)"); return FRIRL_HIP_EINVAL; }
+    (void)frirl_host::opts();
+    frirl_host::g_opts.*(o->field) = value;
+    return FRIRL_HIP_OK;
+}
+
+int frirl_hip_get_option(const char *name, int *value)
+{
+    const frirl_host::OptName *o = frirl_host::find_opt(name);
+    if (!o || !value) { frirl_host::set_error("frirl_hip_get_option: unknown option '%s'", name ? name : "(null)"); return FRIRL_HIP_EINVAL; }
+    *value = frirl_host::opts().*(o->field);
+    return FRIRL_HIP_OK;
+}
 
 int frirl_hip_device_count(void)
 {

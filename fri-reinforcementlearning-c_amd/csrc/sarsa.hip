@@ -317,7 +317,7 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
 // Arithmetic, lane mapping and reduction order are those of the one-wave step kernel => bit-identical results.
 template <int NANT, int AMAX, int CAP>
 __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
-                                                                  double *__restrict__ rb, int32_t *__restrict__ nrules, int maxR,
+                                                                  double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules, int maxR,
                                                                   const frirl_hip_agent ag, const frirl_hip_envs ev, int nsteps)
 {
     constexpr int NS = NANT - 1, BLOCK = FRIRL_WAVE;
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
     agl.grid_values = grid_s;
     const uint32_t episode = ev.episode ? (uint32_t)ev.episode[e] : 0u;
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
+    uint16_t *uidx_e = uidx ? uidx + (size_t)e * NANT * maxR : nullptr;      // 16-bit index mirror: appends are written through (five_add_rule.c:76)
     const ColsLds cols{slab_s, CAP};
     double *qcol = slab_s + (size_t)NANT * CAP;
     const int p = ag.p > 0 ? ag.p : NANT;
@@ -391,7 +392,10 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
         int st = FRIRL_HIP_UPD_INACTIVE;
         if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr, p);
         __syncthreads();
-        if (st == FRIRL_HIP_UPD_INSERTED && rant_e && threadIdx.x < NANT) rant_e[(size_t)threadIdx.x * maxR + (nrules_s - 1)] = sh.rant[threadIdx.x];
+        if (st == FRIRL_HIP_UPD_INSERTED && threadIdx.x < NANT) {
+            if (rant_e) rant_e[(size_t)threadIdx.x * maxR + (nrules_s - 1)] = sh.rant[threadIdx.x];
+            if (uidx_e) uidx_e[(size_t)threadIdx.x * maxR + (nrules_s - 1)] = (uint16_t)sh.idx3[threadIdx.x];
+        }
         if (st == FRIRL_HIP_UPD_FULL) {                // LDS slab full: hand the (unchanged) step back to the caller
             if (threadIdx.x == 0) status_s = FRIRL_HIP_UPD_FULL;
             __syncthreads();
@@ -629,10 +633,21 @@ static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases 
     // one wave per environment: small rule bases, or mid-size ones when the environments alone fill the chip (>= 4 waves
     // per SIMD): measured at 8192 rules x 8192 envs 0.320 -> 0.295 ms per step; at 65 536 rules the 256-thread form wins
     bool small = b->maxR <= 2048 || (b->maxR <= 16384 && b->E >= 4096);
-    if (const char *e = getenv("FRIRL_HIP_STEP_WAVE")) small = atoi(e) == 1 ? true : (atoi(e) == 0 ? false : small);
+    if (frirl_host::opts().step_wave >= 0) small = frirl_host::opts().step_wave == 1;
     if (ag->A <= 4) { if (small) launch_episode_v<N, 4, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 4, 256, BEGIN>(t, b, ag, ev, s); }
     else if (ag->A <= 8) { if (small) launch_episode_v<N, 8, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 8, 256, BEGIN>(t, b, ag, ev, s); }
     else launch_episode_v<N, 32, 256, BEGIN>(t, b, ag, ev, s);            // > 8 actions: action-parallel waves (sweep_gba_wide)
+}
+
+// 1 when frirl_hip_episode_step streams the 16-bit index mirror for this shape (given that the caller provides one)
+extern "C" int frirl_hip_step_uses_uidx(int32_t nant, int32_t U, int32_t maxR, int32_t E)
+{
+    frirl_hip_tables t = {nant, U, nullptr, nullptr};
+    frirl_hip_rulebases b = {E, maxR, nullptr, nullptr, reinterpret_cast<uint16_t *>(16)};
+    if (!frirl::use_uidx(&t, &b)) return 0;
+    bool small = maxR <= 2048 || (maxR <= 16384 && E >= 4096);
+    if (frirl_host::opts().step_wave >= 0) small = frirl_host::opts().step_wave == 1;
+    return !small || sizeof(double) * nant * (size_t)U <= 4096;
 }
 
 static int check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
@@ -720,7 +735,7 @@ static void launch_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
                        int lds_rules, hipStream_t s)
 {
     const size_t dyn = 2 * sizeof(double) * t->nant * (size_t)t->U;
-#define RUN(CAP_) hipLaunchKernelGGL((frirl::episode_run_kernel<N, AMAX, CAP_>), dim3(b->E), dim3(FRIRL_WAVE), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, \
+#define RUN(CAP_) hipLaunchKernelGGL((frirl::episode_run_kernel<N, AMAX, CAP_>), dim3(b->E), dim3(FRIRL_WAVE), dyn, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
                                      b->maxR, *ag, *ev, nsteps)
     if (lds_rules <= 256) RUN(256);
     else if (lds_rules <= 512) RUN(512);

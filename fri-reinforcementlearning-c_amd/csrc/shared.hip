@@ -321,7 +321,7 @@ static void launch_rollout(const frirl_hip_tables *t, const frirl_hip_rulebases 
 // lanes per environment: 1 once the environments alone fill the chip, else split the actions over 4 (A <= 4) or 8 lanes
 static int rollout_group(int Q, int A)
 {
-    if (const char *e = getenv("FRIRL_HIP_ROLLOUT_GROUP")) { const int g = atoi(e); if (g == 1 || (g == 4 && A <= 4) || (g == 8 && A > 4)) return g; }
+    { const int g = frirl_host::opts().rollout_group; if (g == 1 || (g == 4 && A <= 4) || (g == 8 && A > 4)) return g; }
     if (A < 2 || Q >= 131072) return 1;
     return A <= 4 ? 4 : 8;
 }
@@ -331,7 +331,7 @@ static int rollout_group(int Q, int A)
 static int rollout_slices(int Q, int G)
 {
     if (G == 1) return 1;
-    if (const char *e = getenv("FRIRL_HIP_ROLLOUT_SLICES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 8) return v; }
+    { const int v = frirl_host::opts().rollout_slices; if (v == 1 || v == 4 || v == 8) return v; }
     const long waves1 = ((long)Q * G + 63) / 64;
     return waves1 * 8 <= 2048 ? 8 : (waves1 * 4 <= 2048 ? 4 : 1);
 }

@@ -198,7 +198,7 @@ struct ColsSel<true> {
 // table fill would cost more than it saves).
 static inline bool use_uidx(const frirl_hip_tables *t, const frirl_hip_rulebases *b)
 {
-    return b->uidx && t->U <= 65536 && sizeof(double) * t->nant * (size_t)t->U <= 48 * 1024 && b->maxR > 2048 && !getenv("FRIRL_HIP_NO_UIDX");
+    return b->uidx && t->U <= 65536 && sizeof(double) * t->nant * (size_t)t->U <= 48 * 1024 && b->maxR > 2048 && !frirl_host::opts().no_uidx;
 }
 
 // Squared VE distance of two adjacent rules (r, r+1) to the observation q over dims [0, NDIM):

@@ -305,6 +305,9 @@ int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int r
         printf("batch %s: agents %lld episodes %d converged %lld env-steps %lld mean-rules %.3f mean-reward %.6f (min %.6f max %.6f)\n", env,
                (long long)st.agents, episodes, (long long)st.converged, (long long)st.total_env_steps, st.rules_sum / st.agents,
                st.reward_sum / st.agents, st.reward_min, st.reward_max);
+    if (st.full_agents > 0)      /* the reference never checks the capacity (FIVE_add_rule writes past it); here the append is refused and reported */
+        fprintf(stderr, "Warning: %lld of %lld rule bases are at their capacity of %d rules: further rule insertions were refused\n",
+                (long long)st.full_agents, (long long)st.agents, (int)d.maxR);
     if (save_bin) {                               /* all agents' rule bases, before any reduction */
         rc = frirl_hip_batch_save_rulebases(b, save_bin);
         if (rc) five_dropin_fatal("frirl_demo_batch_run(save)", rc);

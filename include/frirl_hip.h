@@ -96,6 +96,17 @@ const char *frirl_hip_last_error(void);
 int frirl_hip_device_count(void);                 /* number of visible gfx950 devices, <0 on error */
 int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, int64_t *hbm_bytes);
 
+/* Experiment / test switches by name: "no_uidx" (1 = ignore the 16-bit index mirror), "rd_unroll", "rd_chunk", "rd_nt",
+ * "rd_persist", "step_wave", "step_envs", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices".  Their defaults
+ * (the shipped configuration) are read ONCE from the matching FRIRL_HIP_<NAME> environment variable, never per launch;
+ * results do not depend on any of them (only the kernel variant / launch shape does). */
+int frirl_hip_set_option(const char *name, int value);
+int frirl_hip_get_option(const char *name, int *value);
+/* Which layout the scans stream for a shape when the caller provides the 16-bit index mirror (bench / tests: the bytes
+ * a launch moves): 1 = compressed indices + LDS tables, 0 = the f64 columns. */
+int five_hip_rule_distance_uses_uidx(int32_t nant, int32_t U);
+int frirl_hip_step_uses_uidx(int32_t nant, int32_t U, int32_t maxR, int32_t E);
+
 /* ---- five_rule_distance (reference src/five/five_rule_distance.c:63-295) -------------------
  * For every environment e: ruledists[e][r] = sqrt(sum_k (ve[k][snap(x[e][k])] - rb[e][k][r])^2),
  * k ascending, for r < nrules[e]; hit[e] = lowest r < nrules[e] with distance exactly 0.0, else
@@ -395,6 +406,8 @@ typedef struct frirl_hip_batch_desc {
 typedef struct frirl_hip_batch_stats_t {
     double reward_sum, steps_sum, rules_sum, reward_min, reward_max;
     int64_t agents, converged, episodes_max, total_env_steps;
+    int64_t full_agents;       /* agents whose rule base is at capacity (numofrules == maxR): further appends are refused
+                                  (FRIRL_HIP_UPD_FULL) and those TD updates dropped -- size maxR so that this stays 0 */
 } frirl_hip_batch_stats_t;
 
 frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d);

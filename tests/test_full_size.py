@@ -173,7 +173,7 @@ def test_run_to_run_determinism():
     assert (outs[0][3] == frirl_amd.UPD_SPREAD).any() or (outs[0][3] == frirl_amd.UPD_INSERTED).any()
 
 
-def test_compressed_index_path_is_bit_identical_to_f64_path(monkeypatch):
+def test_compressed_index_path_is_bit_identical_to_f64_path(hip_option):
     """The 16-bit index mirror (frirl_hip_rulebases.uidx + LDS tables) feeds the kernels the SAME doubles as the f64
     columns (rb[k][r] == ve[k][uidx[k][r]]): every result must be bit-identical between the two paths, and appends
     must keep the mirror in sync."""
@@ -182,10 +182,7 @@ def test_compressed_index_path_is_bit_identical_to_f64_path(monkeypatch):
     En, Rn = 512, 4096
 
     def run(no_uidx):
-        if no_uidx:
-            monkeypatch.setenv("FRIRL_HIP_NO_UIDX", "1")
-        else:
-            monkeypatch.delenv("FRIRL_HIP_NO_UIDX", raising=False)
+        hip_option("no_uidx", 1 if no_uidx else 0)
         prob, agent, envs = frirl_amd.demo_batch("acrobot", En, Rn, Rn + 256, dev, seed=11)
         g = torch.Generator(device="cuda").manual_seed(3)
         lo, hi = prob.u[:, 0], prob.u[:, prob.U - 2]

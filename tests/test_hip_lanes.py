@@ -10,14 +10,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["index-store", "f64-store", "index-store/1-slice", "f64-store/2-slices", "index-store/4-slices"])
-def store(request, monkeypatch):
+def store(request, hip_option):
     """Both rule stores of the lane-group kernel: packed 16-bit universe indices + LDS tables (default when the batch keeps
-    the index mirror) and plain f64 columns (FRIRL_HIP_NO_UIDX=1); rule slices per conclusion: the heuristic's choice (8 for
+    the index mirror) and plain f64 columns (option "no_uidx"); rule slices per conclusion: the heuristic's choice (8 for
     these small batches), or forced to 1 (pure sequential sums, the reference's order) / 2 / 4."""
     if request.param.startswith("f64-store"):
-        monkeypatch.setenv("FRIRL_HIP_NO_UIDX", "1")
+        hip_option("no_uidx", 1)
     if "/" in request.param:
-        monkeypatch.setenv("FRIRL_HIP_LANES_SLICES", request.param.split("/")[1][0])
+        hip_option("lanes_slices", int(request.param.split("/")[1][0]))
     return request.param
 
 

@@ -63,13 +63,12 @@ def test_rollouts_on_shared_rule_base_follow_oracle(env):
     # row 0 = the converged demo's own last episode
     assert success[0] == 1 or env == "cartpole"
     # lanes-per-environment variants (1 = throughput layout, 4 / 8 = actions split over lanes): bit-identical results
-    import os
-    os.environ["FRIRL_HIP_ROLLOUT_GROUP"] = "1"
+    old = frirl_amd.set_option("rollout_group", 1)
     try:
         st1, rw1, _, fin1 = prob.rollout_shared(agent, Q, start_states=torch.from_numpy(s).to(dev))
         torch.cuda.synchronize()
     finally:
-        del os.environ["FRIRL_HIP_ROLLOUT_GROUP"]
+        frirl_amd.set_option("rollout_group", old)
     assert (st1.cpu().numpy() == steps).all() and (rw1.cpu().numpy() == reward).all() and (fin1 == final).all()
     # default start (NULL start_states) = row 0 for every lane
     st2, rw2, _, _ = prob.rollout_shared(agent, 70)

@@ -128,7 +128,7 @@ def test_persistent_episode_kernel_is_bit_identical_to_step_kernel(env):
             torch.cuda.synchronize()
             assert (envs.done == 1).all()
         return [prob.rb.clone(), prob.nrules.clone(), envs.states.clone(), envs.q_ant.clone(), envs.ep_steps.clone(), envs.ep_reward.clone(),
-                envs.fus.clone(), envs.rant.clone()]
+                envs.fus.clone(), envs.rant.clone(), prob.uidx.clone()]       # uidx: the 16-bit mirror must follow LDS appends too
 
     ref = run(False)
     for lds in (256, 1024):
@@ -139,8 +139,42 @@ def test_persistent_episode_kernel_is_bit_identical_to_step_kernel(env):
     if env == "acrobot":
         # force the overflow path: a 256-rule slab is too small once acrobot's rule base grows past it
         prob, agent, envs = frirl_amd.demo_fresh_batch(env, 4, 1024, dev)
-        conv = frirl_amd.train(prob, agent, envs, max_episodes=60, persistent_max_rules=1024)
+        conv = frirl_amd.train(prob, agent, envs, max_episodes=60, persistent_max_rules=1024, lanes=False)
         prob2, agent2, envs2 = frirl_amd.demo_fresh_batch(env, 4, 1024, dev)
-        conv2 = frirl_amd.train(prob2, agent2, envs2, max_episodes=60, persistent=False)
+        conv2 = frirl_amd.train(prob2, agent2, envs2, max_episodes=60, persistent=False, lanes=False)
         torch.cuda.synchronize()
         assert (prob.rb == prob2.rb).all() and (prob.nrules == prob2.nrules).all() and int(prob.nrules.max()) > 256
+        assert (prob.uidx == prob2.uidx).all()
+
+
+@pytest.mark.parametrize("env", ["mountaincar", "acrobot"])
+def test_persistent_episode_kernel_keeps_the_index_mirror_in_sync(env):
+    """frirl_hip_episode_run appends rules in LDS; the 16-bit universe-index mirror (frirl_hip_rulebases.uidx ==
+    FIVERB.rseqant_uindex, five_add_rule.c:76) must follow: afterwards uidx equals the oracle's indices and the
+    compressed rule-distance scan gives the bits of the f64 scan."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    E = 8
+    fr = ob.Frirl(env, trig_mode=1)
+    prob, agent, envs = frirl_amd.demo_fresh_batch(env, E, 1024, dev)
+    for _ in range(4):
+        fr.episode()
+        frirl_amd.episode_begin(prob, agent, envs)
+        frirl_amd.episode_run(prob, agent, envs, agent.desc.max_steps, 1024)
+        torch.cuda.synchronize()
+        assert (envs.done == 1).all()
+    R = fr.five.R
+    assert (prob.nrules == R).all() and R > 2 ** prob.nant
+    got = prob.uidx[:, :, :R].cpu().numpy().astype(np.int64)
+    assert (got == fr.five.uidx[None, :, :R]).all(), "uidx mirror out of sync after LDS appends"
+    # rb[e][k][r] == ve[k][uidx[e][k][r]]
+    ve = prob.ve.cpu().numpy()
+    rb = prob.rb[:, : prob.nant, :R].cpu().numpy()
+    assert (rb == ve[np.arange(prob.nant)[None, :, None], got]).all()
+    x = envs.q_ant.clone()
+    d_idx, h_idx = prob.rule_distance(x)
+    plain = frirl_amd.Problem(prob.u, prob.ve, prob.rb, prob.nrules)          # no mirror: the f64 columns are streamed
+    d_f64, h_f64 = plain.rule_distance(x)
+    torch.cuda.synchronize()
+    assert (h_idx == h_f64).all() and (d_idx[:, :R].view(torch.int64) == d_f64[:, :R].view(torch.int64)).all()

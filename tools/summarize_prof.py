@@ -61,3 +61,29 @@ for ctr, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE
         short = name if len(name) < 90 else name[:87] + "..."
         print(f"| `{short}` | {len(v)} | {avg:.1f} | {avg * 1024:.4g} | {corr:.4g} |")
     print("\nFETCH_SIZE is doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for wide coalesced reads); WRITE_SIZE is exact for 16-B/lane streaming stores.\n")
+
+# SQ / LDS counter passes (sums over all dispatches of a kernel; percentages relative to SQ_WAVE_CYCLES of the same pass)
+for sub in ("pmc_sq", "pmc_lds"):
+    acc = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(int)
+    first = None
+    for p, r in rows(sub + "/**/*counter_collection.csv"):
+        k = r.get("Kernel_Name")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        first = first or r["Counter_Name"]
+        if r["Counter_Name"] == first:
+            calls[k] += 1
+    if not acc:
+        continue
+    print(f"## PMC {sub} (per dispatch averages)\n")
+    key = "SQ_WAVE_CYCLES" if sub == "pmc_sq" else "SQ_LDS_IDX_ACTIVE"
+    for k, c in sorted(acc.items(), key=lambda kv: -sum(kv[1].values()))[:3]:
+        n = max(calls[k], 1)
+        short = k if len(k) < 90 else k[:87] + "..."
+        print(f"`{short}` ({n} dispatches)\n")
+        print("| counter | per dispatch | vs " + key + " |")
+        print("|---|---|---|")
+        base = c.get(key, 0.0) or 1.0
+        for name, v in sorted(c.items()):
+            print(f"| {name} | {v / n:.4g} | {100 * v / base:.1f}% |")
+        print()
