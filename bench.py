@@ -148,14 +148,15 @@ def cpu_baseline(w, budget_s=18.0):
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     t0 = time.time()
     if os.path.exists(harness) and nant <= 8:
-        cal = _harness_bench(harness, nant, U, R, 32)                              # calibration: 32 queries (tens of ms)
-        rate_q = 32.0 / max(cal["rule_distance_s"] + cal["vag_concl_s"], 1e-6)     # queries per second incl. the Shepard leg
-        nq = max(64, int(0.40 * budget_s * rate_q))                                # one-core leg: ~40 % of the budget
+        ncal = max(32, int(2.0e7 / R))                                             # calibration: ~0.1-0.3 s, past the first-touch effects
+        cal = _harness_bench(harness, nant, U, R, ncal)
+        rate_q = ncal / max(cal["rule_distance_s"] + cal["vag_concl_s"], 1e-6)     # queries per second incl. the Shepard leg (1/8 of the queries)
+        nq = max(64, int(0.45 * budget_s * rate_q))                                # one-core leg: ~45 % of the budget
         rec = _harness_bench(harness, nant, U, R, nq)
         # the reference's own parallel model is one private rule base per agent/core (frirl_agent.c:309-325): one harness
         # process per host core at the same time (~25 % of the budget) and the rates added up
         ncores = max(1, min(len(os.sched_getaffinity(0)), 16))    # the GPU box gives one GPU a 16-core share
-        nq_all = max(64, int(0.25 * budget_s * rate_q))
+        nq_all = max(64, int(0.30 * budget_s * rate_q))
         procs = [subprocess.Popen([harness, "bench", str(nant), str(U), str(R), str(nq_all)], stdout=subprocess.PIPE, text=True) for _ in range(ncores)]
         allc = 0.0
         for pr in procs:
@@ -389,8 +390,8 @@ def learning_and_evaluation(B, w, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="override environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

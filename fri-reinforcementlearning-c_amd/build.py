@@ -18,7 +18,8 @@ HIP_LIB = os.path.join(LIBDIR, "libfrirl_hip.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-             "-ffp-contract=off",      # reference uses separate vmulpd/vaddpd: no FMA contraction anywhere
+             "-ffp-contract=off",      # no IMPLICIT contraction: distances, snaps and env dynamics keep separate mul / add like the
+             # reference's vmulpd/vaddpd (bit-exact); the Q sweeps use EXPLICIT __fma_rn inside their <= 1e-6 contract
              "-Wall", "-Wno-unused-function"]
 
 
@@ -71,7 +72,7 @@ def build_host(force=False, verbose=False):
     deps = srcs + glob.glob(os.path.join(HOST_DIR, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + [HIP_LIB]
     inc = ["-I", os.path.join(ROOT, "include"), "-I", HOST_DIR]
     if force or _stale(DROPIN_LIB, deps):
-        cmd = [CC] + HOST_CFLAGS + inc + ["-shared", "-o", DROPIN_LIB] + srcs + ["-L", LIBDIR, "-lfrirl_hip", "-Wl,-rpath,$ORIGIN", "-lm"]
+        cmd = [CC] + HOST_CFLAGS + inc + ["-shared", "-o", DROPIN_LIB] + srcs + ["-L", LIBDIR, "-lfrirl_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"]
         if verbose:
             print("+", " ".join(cmd))
         subprocess.run(cmd, check=True)

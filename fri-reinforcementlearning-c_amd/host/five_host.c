@@ -9,20 +9,28 @@
  * (the reference's own error convention is printf + exit, e.g. FIVEInit.c:61-64).
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "dropin_internal.h"
 
-/* ---- FIVERB -> mirror side table ---------------------------------------------------------- */
-#define MAX_MIRRORS 256
+/* ---- FIVERB -> mirror side table ----------------------------------------------------------
+ * The only state shared between rule bases; guarded, so that distinct FIVERB / frirl_desc instances can be driven from
+ * different threads (the reference's frirl_omp_run model: one agent per thread, frirl_agent.c:309-325). */
+#define MAX_MIRRORS 1024
 static struct { struct FIVERB *frb; five_hip_mirror *m; } g_mirrors[MAX_MIRRORS];
+static pthread_mutex_t g_mirrors_lock = PTHREAD_MUTEX_INITIALIZER;
 
 five_hip_mirror *five_dropin_mirror(struct FIVERB *frb)
 {
     int i;
-    for (i = 0; i < MAX_MIRRORS; i++) if (g_mirrors[i].frb == frb) return g_mirrors[i].m;
+    five_hip_mirror *m = NULL;
+    pthread_mutex_lock(&g_mirrors_lock);
+    for (i = 0; i < MAX_MIRRORS; i++) if (g_mirrors[i].frb == frb) { m = g_mirrors[i].m; break; }
+    pthread_mutex_unlock(&g_mirrors_lock);
+    if (m) return m;
     fprintf(stderr, "FIVE: rule base %p was not created by FIVEInit of this library\n", (void *)frb);
     exit(30);
 }
@@ -30,7 +38,10 @@ five_hip_mirror *five_dropin_mirror(struct FIVERB *frb)
 static void mirror_register(struct FIVERB *frb, five_hip_mirror *m)
 {
     int i;
-    for (i = 0; i < MAX_MIRRORS; i++) if (!g_mirrors[i].frb) { g_mirrors[i].frb = frb; g_mirrors[i].m = m; return; }
+    pthread_mutex_lock(&g_mirrors_lock);
+    for (i = 0; i < MAX_MIRRORS; i++) if (!g_mirrors[i].frb) { g_mirrors[i].frb = frb; g_mirrors[i].m = m; break; }
+    pthread_mutex_unlock(&g_mirrors_lock);
+    if (i < MAX_MIRRORS) return;
     fprintf(stderr, "FIVE: too many live rule bases (%d)\n", MAX_MIRRORS);
     exit(31);
 }
@@ -38,7 +49,11 @@ static void mirror_register(struct FIVERB *frb, five_hip_mirror *m)
 static void mirror_unregister(struct FIVERB *frb)
 {
     int i;
-    for (i = 0; i < MAX_MIRRORS; i++) if (g_mirrors[i].frb == frb) { five_hip_mirror_destroy(g_mirrors[i].m); g_mirrors[i].frb = 0; g_mirrors[i].m = 0; }
+    five_hip_mirror *m = NULL;
+    pthread_mutex_lock(&g_mirrors_lock);
+    for (i = 0; i < MAX_MIRRORS; i++) if (g_mirrors[i].frb == frb) { m = g_mirrors[i].m; g_mirrors[i].frb = 0; g_mirrors[i].m = 0; break; }
+    pthread_mutex_unlock(&g_mirrors_lock);
+    if (m) five_hip_mirror_destroy(m);
 }
 
 void five_dropin_fatal(const char *where, int rc)

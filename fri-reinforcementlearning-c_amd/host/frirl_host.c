@@ -237,7 +237,7 @@ void frirl_update_sarsa(struct frirl_desc *frirl, fri_float *q_ant, fri_float re
 {
     struct FIVERB *frb = frirl->fiverb;
     frirl_hip_agent ag;
-    static double grid[FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID];
+    double grid[FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID];      /* per call, on the stack: distinct frirl_desc instances stay independent (threads) */
     double new_rant[FRIRL_HIP_MAX_NANT], new_rconc = 0.0;
     int32_t fus = (frirl->fus_is_rule_inserted != 0.0), status = 0;
     int rc;
@@ -282,7 +282,7 @@ void frirl_episode(struct frirl_desc *frirl)
         if (frirl->original_learning != 0 && frirl->reduction_state == 0 && (frirl->no_random == 1 || frirl->epsilon == 0.0)) {
             /* greedy learning step (every shipped demo): frirl_get_best_action (:148) and frirl_update_sarsa (:159) as ONE
              * GPU launch and one synchronisation; same kernels' arithmetic as the two separate calls */
-            static double grid[FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID];
+            double grid[FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID];
             frirl_hip_agent ag;
             double new_rant[FRIRL_HIP_MAX_NANT], new_rconc = 0.0;
             int32_t fus = (frirl->fus_is_rule_inserted != 0.0), status = 0;

@@ -7,6 +7,11 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+ONLY_OURS = "--all" not in sys.argv      # torch's input-generation kernels are noise in these summaries
+
+
+def ours(name):
+    return (not ONLY_OURS) or (name is not None and "frirl::" in name)
 
 
 def rows(pattern):
@@ -19,13 +24,23 @@ def rows(pattern):
 print(f"# rocprofv3 summary: {os.path.basename(out)}\n")
 bj = os.path.join(out, "bench_trace.json")
 if os.path.exists(bj):
-    print("bench line (profiled run):\n```\n" + open(bj).read().strip() + "\n```\n")
+    try:
+        import json
+        rec = json.loads([l for l in open(bj).read().splitlines() if l.startswith("{")][-1])
+        rf = rec["roofline"]
+        print(f"bench line of the profiled run: workload {rec['config']['workload']} (E {rec['config']['envs_per_gpu']}, R {rec['config']['rules_per_env']}), "
+              f"{rec['value']:.4g} evals/s, kernel {rf['kernel']}: avg launch {rf['avg_launch_ms']:.4f} ms (HIP events), moved {rf['algorithmic_bytes_per_launch']:.4g} B "
+              f"-> {rf['achieved']:.0f} GB/s = {rf['frac']:.3f} of 8 TB/s" + (f"; f64 layout {rf['f64_layout']['avg_launch_ms']:.4f} ms = {rf['f64_layout']['frac']:.3f}" if 'f64_layout' in rf else "") + "\n")
+    except Exception as ex:      # keep the raw line if the format changes
+        print("bench line (profiled run):\n```\n" + open(bj).read().strip()[:3000] + "\n```\n")
 
 # kernel stats from the kernel trace
 dur = defaultdict(list)
 meta = {}
 for p, r in rows("trace/**/*kernel_trace.csv"):
     name = r.get("Kernel_Name") or r.get("Name")
+    if not ours(name):
+        continue
     try:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     except (KeyError, ValueError):
@@ -47,7 +62,7 @@ print()
 for ctr, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
     acc = defaultdict(list)
     for p, r in rows(pat):
-        if r.get("Counter_Name") != ctr:
+        if r.get("Counter_Name") != ctr or not ours(r.get("Kernel_Name")):
             continue
         acc[r.get("Kernel_Name")].append(float(r["Counter_Value"]))
     if not acc:
@@ -69,6 +84,8 @@ for sub in ("pmc_sq", "pmc_lds"):
     first = None
     for p, r in rows(sub + "/**/*counter_collection.csv"):
         k = r.get("Kernel_Name")
+        if not ours(k):
+            continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         first = first or r["Counter_Name"]
         if r["Counter_Name"] == first:
@@ -77,7 +94,7 @@ for sub in ("pmc_sq", "pmc_lds"):
         continue
     print(f"## PMC {sub} (per dispatch averages)\n")
     key = "SQ_WAVE_CYCLES" if sub == "pmc_sq" else "SQ_LDS_IDX_ACTIVE"
-    for k, c in sorted(acc.items(), key=lambda kv: -sum(kv[1].values()))[:3]:
+    for k, c in sorted(acc.items(), key=lambda kv: -sum(kv[1].values()))[:4]:
         n = max(calls[k], 1)
         short = k if len(k) < 90 else k[:87] + "..."
         print(f"`{short}` ({n} dispatches)\n")
