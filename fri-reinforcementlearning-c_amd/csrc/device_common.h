@@ -105,7 +105,8 @@ struct Options {
     int rd_unroll;        // rule-distance scan: column sets in flight per lane, 0 = shipped     (FRIRL_HIP_RD_UNROLL)
     int rd_chunk;         // rule-distance scan: rules per workgroup, 0 = shipped                (FRIRL_HIP_RD_CHUNK)
     int rd_nt;            // rule-distance scan: non-temporal variant, -1 = shipped              (FRIRL_HIP_RD_NT)
-    int rd_persist;       // compressed rule-distance scan: -1 = shipped choice, 0 = one workgroup per chunk, 1 = persistent (FRIRL_HIP_RD_PERSIST)
+    int rd_persist;       // compressed rule-distance scan: -1 = by table size, 0 = one workgroup per item, 1 = persistent (FRIRL_HIP_RD_PERSIST)
+    int rd_order;         // rule-distance scan item order: 0 = chunk index fastest (shipped), 1 = environment fastest (FRIRL_HIP_RD_ORDER)
     int step_wave;        // episode step: 1 = one wave per environment, 0 = 256 threads, -1 = by shape (FRIRL_HIP_STEP_WAVE)
     int step_envs;        // episode step: environments per workgroup (wave-per-environment form), 0 = by shape (FRIRL_HIP_STEP_ENVS)
     int lanes_slices;     // lane groups: rule slices per conclusion, 0 = by shape               (FRIRL_HIP_LANES_SLICES)

@@ -29,6 +29,7 @@ static const OptName k_opts[] = {
     {"rd_chunk", "FRIRL_HIP_RD_CHUNK", &Options::rd_chunk, 0},
     {"rd_nt", "FRIRL_HIP_RD_NT", &Options::rd_nt, -1},
     {"rd_persist", "FRIRL_HIP_RD_PERSIST", &Options::rd_persist, -1},
+    {"rd_order", "FRIRL_HIP_RD_ORDER", &Options::rd_order, 0},
     {"step_wave", "FRIRL_HIP_STEP_WAVE", &Options::step_wave, -1},
     {"step_envs", "FRIRL_HIP_STEP_ENVS", &Options::step_envs, 0},
     {"lanes_slices", "FRIRL_HIP_LANES_SLICES", &Options::lanes_slices, 0},

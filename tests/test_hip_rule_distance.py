@@ -133,3 +133,45 @@ def test_full_size_cfg2_properties():
     d_ref, hit_ref = small.oracle_rule_distance(np.ascontiguousarray(xs))
     assert (hit[:16].cpu().numpy() == hit_ref).all()
     assert (bits(d[:16].cpu().numpy()) == bits(d_ref)).all()
+
+
+VARIANT_CASES = [(3, 41, 20000, 5, 3), (5, 1001, 4099, 9, 21), (16, 201, 3000, 3, 0), (16, 1001, 70001, 3, 0), (8, 1001, 5000, 3, 0), (5, 41, 367, 40, 3)]
+
+
+@pytest.mark.parametrize("persist", [0, 1])
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("nant,U,R,E,A", VARIANT_CASES)
+def test_every_launch_form_is_bit_exact(nant, U, R, E, A, persist, order, hip_option):
+    """The three launch forms of the scan -- one workgroup per (environment, chunk) item in chunk-fastest (shipped) or
+    environment-fastest order, and the persistent form (table filled once, items from an in-order counter, observation VE
+    values precomputed) -- forced for every shape through the "rd_persist" / "rd_order" options: same bits, same hit indices,
+    also when the item count is not a multiple of the hand-out batch, with ragged / empty / odd rule bases."""
+    tab = nant * U * 8
+    if persist == 0 and tab > 64 * 1024:
+        pytest.skip("one workgroup per item needs the table copy in 64 KiB")
+    b = Batch(nant, U, R, E, A=A, seed=500 + nant + R, ragged=True)
+    x = b.queries(seed=R + 9, hit_fraction=0.5)
+    d_ref, hit_ref = b.oracle_rule_distance(x)
+    hip_option("rd_persist", persist)
+    hip_option("rd_order", order)
+    for compressed in (True, False):
+        d, hit = run_case(b, x, compressed=compressed)
+        assert (hit.astype(np.int64) == hit_ref.astype(np.int64)).all(), (compressed, hit, hit_ref)
+        for e in range(E):
+            n = int(b.nrules[e])
+            assert (bits(d[e, :n]) == bits(d_ref[e, :n])).all(), (compressed, e)
+        _, hit2 = run_case(b, x, materialise=False, compressed=compressed)
+        assert (hit2 == hit).all()
+
+
+def test_persistent_form_many_environments_few_rules(hip_option):
+    """Persistent form with more items than resident workgroups and a tiny last batch: 3000 environments x 600 rules."""
+    hip_option("rd_persist", 1)
+    b = Batch(5, 41, 600, 3000, A=3, seed=8, ragged=True)
+    x = b.queries(seed=2, hit_fraction=0.3)
+    d_ref, hit_ref = b.oracle_rule_distance(x)
+    d, hit = run_case(b, x, compressed=True)
+    assert (hit.astype(np.int64) == hit_ref.astype(np.int64)).all()
+    for e in range(0, b.E, 7):
+        n = int(b.nrules[e])
+        assert (bits(d[e, :n]) == bits(d_ref[e, :n])).all(), e

@@ -1,6 +1,6 @@
 // rd_bench.hip -- stand-alone A/B harness for variants of the compressed rule-distance scan (round 2).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o rd_bench rd_bench.hip
-//   ./rd_bench <cfg2|cfg3|cfg4|cfg5> [E-override]
+//   ./rd_bench <cfg2|cfg3|cfg4|cfg5> [E-override|0] [maxR pad]
 // Every variant is checked bit for bit against the round-1 kernel (V0) on the same inputs before it is timed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,15 +37,15 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 }
 
 // ---- V0: the round-1 kernel (one workgroup per (env, 2048-rule chunk), VE table refilled per workgroup) ---------------
-template <int NANT, int UNROLL, int BLOCK>
+template <int NANT, int UNROLL, int BLOCK, bool CF = false>
 __global__ __launch_bounds__(BLOCK) void v0_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U, const uint16_t *__restrict__ uidx,
                                                     const int32_t *__restrict__ nrules, int maxR, const double *__restrict__ x, double *__restrict__ dists,
                                                     uint32_t *__restrict__ hit, int rules_per_block)
 {
     extern __shared__ double tab_s[];
-    const int e = blockIdx.x;
+    const int e = CF ? blockIdx.y : blockIdx.x;
     const int R = nrules[e];
-    const int r0 = blockIdx.y * rules_per_block;
+    const int r0 = (CF ? blockIdx.x : blockIdx.y) * rules_per_block;
     if (r0 >= R) return;
     int r_end = r0 + rules_per_block;
     if (r_end > R) r_end = R;
@@ -261,6 +261,232 @@ __global__ __launch_bounds__(BLOCK) void v1_kernel(const double *__restrict__ u,
     }
 }
 
+// ---- V2: persistent workgroups, VE table filled ONCE per workgroup, items = (env, 2-KiB-of-indices chunk) with the chunk
+// index fastest and strided over the workgroups (the chip sweeps a few consecutive environments at a time: contiguous
+// DRAM windows), observation VE values precomputed per environment (qv, written by observe_kernel together with the
+// hit reset) => no per-item barrier, no per-item LDS write, no dependent global chain in the main kernel.
+__global__ void observe_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U, int nant, int E, const double *__restrict__ x,
+                               double *__restrict__ qv, uint32_t *__restrict__ hit)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * nant) return;
+    const int e = i / nant, k = i - e * nant;
+    qv[i] = observe_ve(u, ve, U, k, x[i]);
+    if (k == 0) hit[e] = NO_HIT;
+}
+
+template <int NANT, int BLOCK, int UNR, bool PF>
+__global__ __launch_bounds__(BLOCK) void v2_kernel(const double *__restrict__ ve, int U, const uint16_t *__restrict__ uidx, const int32_t *__restrict__ nrules,
+                                                    int maxR, const double *__restrict__ qv, double *__restrict__ dists, uint32_t *__restrict__ hit,
+                                                    int cpe, int nitems)
+{
+    extern __shared__ double tab_s[];            // [NANT][U] vague environments
+    constexpr int STEP = BLOCK * 2, CH = STEP * UNR;
+    uint32_t w[UNR][NANT];
+    int item = blockIdx.x;
+    auto load_item = [&](int it) {
+        const int e = it / cpe, c = it - e * cpe;
+        const int R = nrules[e];
+        const uint16_t *__restrict__ base = uidx + (size_t)e * NANT * maxR;
+        const int r = c * CH + 2 * (int)threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            const int rr = r + j * STEP;
+            if (rr < R) {
+#pragma unroll
+                for (int k = 0; k < NANT; k++) w[j][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(base + (size_t)k * maxR + rr));
+            }
+        }
+    };
+    if (item < nitems) load_item(item);
+    for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
+    __syncthreads();
+    for (; item < nitems; item += gridDim.x) {
+        const int e = item / cpe, c = item - e * cpe;
+        const int R = nrules[e];
+        uint32_t cw[UNR][NANT];
+#pragma unroll
+        for (int j = 0; j < UNR; j++)
+#pragma unroll
+            for (int k = 0; k < NANT; k++) cw[j][k] = w[j][k];
+        const int nxt = item + gridDim.x;
+        if (PF && nxt < nitems) load_item(nxt);
+        double q[NANT];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) q[k] = qv[(size_t)e * NANT + k];
+        double *__restrict__ out = dists + (size_t)e * maxR;
+        const int r = c * CH + 2 * (int)threadIdx.x;
+        unsigned best = NO_HIT;
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            const int rr = r + j * STEP;
+            if (rr < R) {
+                double d0 = q[0] - tab_s[cw[j][0] & 0xFFFFu], d1 = q[0] - tab_s[cw[j][0] >> 16];
+                double a0 = d0 * d0, a1 = d1 * d1;
+#pragma unroll
+                for (int k = 1; k < NANT; k++) {
+                    d0 = q[k] - tab_s[k * U + (cw[j][k] & 0xFFFFu)];
+                    d1 = q[k] - tab_s[k * U + (cw[j][k] >> 16)];
+                    const double s0 = d0 * d0, s1 = d1 * d1;
+                    a0 = a0 + s0;
+                    a1 = a1 + s1;
+                }
+                double2 d;
+                d.x = __dsqrt_rn(a0);
+                d.y = __dsqrt_rn(a1);
+                __builtin_nontemporal_store(d.x, out + rr);
+                __builtin_nontemporal_store(d.y, out + rr + 1);
+                if (d.y == 0.0 && rr + 1 < R) best = min(best, (unsigned)(rr + 1));
+                if (d.x == 0.0) best = min(best, (unsigned)rr);
+            }
+        }
+        if (best != NO_HIT) atomicMin(&hit[e], best);        // rare
+        if (!PF && nxt < nitems) load_item(nxt);
+    }
+}
+
+// ---- V3: V2 + in-order dynamic item hand-out (one atomic per KB consecutive items, so that the workgroups advance as one
+// compact window over memory like hardware workgroup dispatch does) + the next item's scalars (rule count, observation VE
+// values) fetched one item ahead together with its indices.
+template <int NANT, int BLOCK, int UNR, int KB, bool DYN>
+__global__ __launch_bounds__(BLOCK) void v3_kernel(const double *__restrict__ ve, int U, const uint16_t *__restrict__ uidx, const int32_t *__restrict__ nrules,
+                                                    int maxR, const double *__restrict__ qv, double *__restrict__ dists, uint32_t *__restrict__ hit,
+                                                    int cpe, int nitems, unsigned *__restrict__ counter)
+{
+    extern __shared__ double tab_s[];            // [NANT][U] vague environments
+    __shared__ int batch_s[2];
+    constexpr int STEP = BLOCK * 2, CH = STEP * UNR;
+    uint32_t w[UNR][NANT];
+    double qn[NANT];
+    int en = 0, cn = 0, Rn = 0;
+    // item sequence of this workgroup: batches of KB consecutive items; batch b -> items [b*KB, (b+1)*KB)
+    int slot = 0;
+    int batch, sub = 0;
+    if (DYN) {
+        if (threadIdx.x == 0) batch_s[0] = (int)atomicAdd(counter, 1u);
+        __syncthreads();
+        batch = batch_s[0];
+    } else batch = blockIdx.x;
+    const int nbatches = (nitems + KB - 1) / KB;
+    auto load_item = [&](int it) {
+        en = it / cpe; cn = it - en * cpe;
+        Rn = nrules[en];
+        const uint16_t *__restrict__ base = uidx + (size_t)en * NANT * maxR;
+        const int r = cn * CH + 2 * (int)threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            const int rr = r + j * STEP;
+            if (rr < Rn) {
+#pragma unroll
+                for (int k = 0; k < NANT; k++) w[j][k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(base + (size_t)k * maxR + rr));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NANT; k++) qn[k] = qv[(size_t)en * NANT + k];
+    };
+    int item = batch < nbatches ? batch * KB : nitems;
+    if (item < nitems) load_item(item);
+    for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
+    __syncthreads();
+    while (item < nitems) {
+        const int e = en, c = cn, R = Rn;
+        uint32_t cw[UNR][NANT];
+        double q[NANT];
+#pragma unroll
+        for (int j = 0; j < UNR; j++)
+#pragma unroll
+            for (int k = 0; k < NANT; k++) cw[j][k] = w[j][k];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) q[k] = qn[k];
+        // next item: inside the batch, or the first item of the next batch
+        int nxt;
+        sub++;
+        if (sub < KB && item + 1 < nitems) nxt = item + 1;
+        else {
+            sub = 0;
+            if (DYN) {
+                slot ^= 1;
+                if (threadIdx.x == 0) batch_s[slot] = (int)atomicAdd(counter, 1u);
+                __syncthreads();
+                batch = batch_s[slot];
+            } else batch += gridDim.x;
+            nxt = batch < nbatches ? batch * KB : nitems;
+        }
+        if (nxt < nitems) load_item(nxt);
+        double *__restrict__ out = dists + (size_t)e * maxR;
+        const int r = c * CH + 2 * (int)threadIdx.x;
+        unsigned best = NO_HIT;
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            const int rr = r + j * STEP;
+            if (rr < R) {
+                double d0 = q[0] - tab_s[cw[j][0] & 0xFFFFu], d1 = q[0] - tab_s[cw[j][0] >> 16];
+                double a0 = d0 * d0, a1 = d1 * d1;
+#pragma unroll
+                for (int k = 1; k < NANT; k++) {
+                    d0 = q[k] - tab_s[k * U + (cw[j][k] & 0xFFFFu)];
+                    d1 = q[k] - tab_s[k * U + (cw[j][k] >> 16)];
+                    const double s0 = d0 * d0, s1 = d1 * d1;
+                    a0 = a0 + s0;
+                    a1 = a1 + s1;
+                }
+                double2 d;
+                d.x = __dsqrt_rn(a0);
+                d.y = __dsqrt_rn(a1);
+                __builtin_nontemporal_store(d.x, out + rr);
+                __builtin_nontemporal_store(d.y, out + rr + 1);
+                if (d.y == 0.0 && rr + 1 < R) best = min(best, (unsigned)(rr + 1));
+                if (d.x == 0.0) best = min(best, (unsigned)rr);
+            }
+        }
+        if (best != NO_HIT) atomicMin(&hit[e], best);        // rare
+        item = nxt;
+    }
+}
+
+// ---- V9: traffic ceiling -- the same loads and stores as V0 (2*NANT B read, 8 B written per rule), no LDS, no sqrt --------
+// MODE 0: reads + writes, 1: reads only (one word per lane written at the end), 2: writes only.  CF: chunk index fastest in the grid.
+template <int NANT, int UNROLL, int BLOCK, int MODE = 0, bool CF = false>
+__global__ __launch_bounds__(BLOCK) void v9_kernel(const uint16_t *__restrict__ uidx, const int32_t *__restrict__ nrules, int maxR, double *__restrict__ dists, int rules_per_block)
+{
+    const int e = CF ? blockIdx.y : blockIdx.x;
+    const int R = nrules[e];
+    const int r0 = (CF ? blockIdx.x : blockIdx.y) * rules_per_block;
+    if (r0 >= R) return;
+    int r_end = r0 + rules_per_block;
+    if (r_end > R) r_end = R;
+    const uint16_t *__restrict__ base = uidx + (size_t)e * NANT * maxR;
+    double *__restrict__ out = dists + (size_t)e * maxR;
+    constexpr int STEP = BLOCK * 2;
+    uint32_t acc = 0;
+    for (int r = r0 + 2 * (int)threadIdx.x; r < r_end; r += STEP * UNROLL) {
+        uint32_t w[UNROLL][NANT];
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) {
+            const int rr = r + j * STEP;
+            if (rr < r_end) {
+#pragma unroll
+                for (int k = 0; k < NANT; k++) w[j][k] = (MODE == 2) ? (uint32_t)(rr + k) : __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(base + (size_t)k * maxR + rr));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; j++) {
+            const int rr = r + j * STEP;
+            if (rr < r_end) {
+                uint32_t a = 0;
+#pragma unroll
+                for (int k = 0; k < NANT; k++) a += w[j][k];
+                if (MODE == 1) acc += a;
+                else {
+                    __builtin_nontemporal_store((double)(a & 0xFFFFu), out + rr);
+                    __builtin_nontemporal_store((double)(a >> 16), out + rr + 1);
+                }
+            }
+        }
+    }
+    if (MODE == 1 && acc == 0x12345678u) out[r0] = 1.0;      // never true in practice: keeps the loads alive
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------
 struct Cfg { const char *name; int nant, U, R, E; };
 static const Cfg CFGS[] = {{"cfg2", 3, 41, 8192, 8192}, {"cfg3", 5, 1001, 32768, 32768}, {"cfg4", 5, 41, 65536, 8192}, {"cfg5", 16, 1001, 262144, 64}};
@@ -344,6 +570,103 @@ static void v1(Ctx &C, int wg_per_cu, int chunk_target, size_t bytes)
     run_variant(C, name, bytes, [&] { hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), tab, 0, C.u, C.ve, C.c.U, C.uidx, C.nrules, C.maxR, C.x, C.d_out, C.hit, chunk, cpe, nitems); });
 }
 
+template <int NANT, int BLOCK, int UNR, bool PF>
+static void v2(Ctx &C, int wg_per_cu, size_t bytes, double *qv)
+{
+    const int tab = 8 * NANT * C.c.U;
+    auto k = v2_kernel<NANT, BLOCK, UNR, PF>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, tab));
+    const int CH = BLOCK * 2 * UNR;
+    const int cpe = (C.maxR + CH - 1) / CH;
+    const int nitems = cpe * C.c.E;
+    int grid = 256 * wg_per_cu;
+    if (wg_per_cu <= 0 || grid > nitems) grid = nitems;       // wg_per_cu 0: one workgroup per item (not persistent)
+    char name[128];
+    snprintf(name, sizeof name, "V2 B%d U%d %s wg/cu %d (chunk %d, %d items)", BLOCK, UNR, PF ? "PF" : "--", wg_per_cu, CH, nitems);
+    const int nq = C.c.E * NANT;
+    run_variant(C, name, bytes, [&] {
+        hipLaunchKernelGGL(observe_kernel, dim3((nq + 255) / 256), dim3(256), 0, 0, C.u, C.ve, C.c.U, NANT, C.c.E, C.x, qv, C.hit);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), tab, 0, C.ve, C.c.U, C.uidx, C.nrules, C.maxR, qv, C.d_out, C.hit, cpe, nitems);
+    });
+}
+
+template <int NANT, int BLOCK, int UNR, int KB, bool DYN>
+static void v3(Ctx &C, int wg_per_cu, size_t bytes, double *qv, unsigned *counter)
+{
+    const int tab = 8 * NANT * C.c.U;
+    auto k = v3_kernel<NANT, BLOCK, UNR, KB, DYN>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, tab));
+    const int CH = BLOCK * 2 * UNR;
+    const int cpe = (C.maxR + CH - 1) / CH;
+    const int nitems = cpe * C.c.E;
+    int grid = 256 * wg_per_cu;
+    const int nb = (nitems + KB - 1) / KB;
+    if (grid > nb) grid = nb;
+    char name[128];
+    snprintf(name, sizeof name, "V3 B%d U%d KB%d %s wg/cu %d (chunk %d)", BLOCK, UNR, KB, DYN ? "dyn" : "sta", wg_per_cu, CH);
+    const int nq = C.c.E * NANT;
+    run_variant(C, name, bytes, [&] {
+        CK(hipMemsetAsync(counter, 0, 4));
+        hipLaunchKernelGGL(observe_kernel, dim3((nq + 255) / 256), dim3(256), 0, 0, C.u, C.ve, C.c.U, NANT, C.c.E, C.x, qv, C.hit);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), tab, 0, C.ve, C.c.U, C.uidx, C.nrules, C.maxR, qv, C.d_out, C.hit, cpe, nitems, counter);
+    });
+}
+
+template <typename F>
+static double time_only(F launch)
+{
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ts;
+    launch(); CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < 5; rep++) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 10; i++) launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / 10);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[2];
+}
+
+// access-pattern sweep: grid order (environment-fastest / chunk-fastest) x chunk size, for the traffic-only kernel (reads +
+// writes, reads only, writes only) and for V0; run once per maxR pad from the command line
+template <int NANT>
+static void run_sweep(Ctx &C)
+{
+    const double ev = (double)C.c.E * C.c.R;
+    const double bytes = ev * (2 * NANT + 8), rbytes = ev * 2 * NANT, wbytes = ev * 8;
+    const int tab = 8 * NANT * C.c.U;
+    constexpr int UN = (NANT <= 8 ? 4 : 2);
+    for (int rpb : {2048, 4096, 8192}) {
+        const int chunks = (C.maxR + rpb - 1) / rpb;
+        dim3 ge(C.c.E, chunks), gc(chunks, C.c.E);
+        double t;
+        t = time_only([&] { hipLaunchKernelGGL((v9_kernel<NANT, UN, 256, 0, false>), ge, dim3(256), 0, 0, C.uidx, C.nrules, C.maxR, C.d_out, rpb); });
+        printf("pad %-5d chunk %-5d env-fastest   traffic r+w %8.4f ms %6.0f GB/s %.3f", C.maxR - C.c.R, rpb, t, bytes / t / 1e6, bytes / t / 8e9);
+        t = time_only([&] { hipLaunchKernelGGL((v9_kernel<NANT, UN, 256, 1, false>), ge, dim3(256), 0, 0, C.uidx, C.nrules, C.maxR, C.d_out, rpb); });
+        printf(" | r %6.0f GB/s", rbytes / t / 1e6);
+        t = time_only([&] { hipLaunchKernelGGL((v9_kernel<NANT, UN, 256, 2, false>), ge, dim3(256), 0, 0, C.uidx, C.nrules, C.maxR, C.d_out, rpb); });
+        printf(" | w %6.0f GB/s", wbytes / t / 1e6);
+        if (tab <= 48 * 1024) {
+            t = time_only([&] { CK(hipMemsetAsync(C.hit, 0xFF, 4 * C.c.E)); hipLaunchKernelGGL((v0_kernel<NANT, UN, 256, false>), ge, dim3(256), tab, 0, C.u, C.ve, C.c.U, C.uidx, C.nrules, C.maxR, C.x, C.d_out, C.hit, rpb); });
+            printf(" | V0 %8.4f ms %.3f", t, bytes / t / 8e9);
+        }
+        printf("\n");
+        t = time_only([&] { hipLaunchKernelGGL((v9_kernel<NANT, UN, 256, 0, true>), gc, dim3(256), 0, 0, C.uidx, C.nrules, C.maxR, C.d_out, rpb); });
+        printf("pad %-5d chunk %-5d chunk-fastest traffic r+w %8.4f ms %6.0f GB/s %.3f", C.maxR - C.c.R, rpb, t, bytes / t / 1e6, bytes / t / 8e9);
+        t = time_only([&] { hipLaunchKernelGGL((v9_kernel<NANT, UN, 256, 1, true>), gc, dim3(256), 0, 0, C.uidx, C.nrules, C.maxR, C.d_out, rpb); });
+        printf(" | r %6.0f GB/s", rbytes / t / 1e6);
+        t = time_only([&] { hipLaunchKernelGGL((v9_kernel<NANT, UN, 256, 2, true>), gc, dim3(256), 0, 0, C.uidx, C.nrules, C.maxR, C.d_out, rpb); });
+        printf(" | w %6.0f GB/s", wbytes / t / 1e6);
+        if (tab <= 48 * 1024) {
+            t = time_only([&] { CK(hipMemsetAsync(C.hit, 0xFF, 4 * C.c.E)); hipLaunchKernelGGL((v0_kernel<NANT, UN, 256, true>), gc, dim3(256), tab, 0, C.u, C.ve, C.c.U, C.uidx, C.nrules, C.maxR, C.x, C.d_out, C.hit, rpb); });
+            printf(" | V0 %8.4f ms %.3f", t, bytes / t / 8e9);
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+}
+
 template <int NANT>
 static void run_cfg(Ctx &C)
 {
@@ -376,7 +699,84 @@ static void run_cfg(Ctx &C)
         dim3 g(C.c.E, (C.maxR + rpb - 1) / rpb);
         run_variant(C, "V0 round-1 (B1024 U2 chunk 32768)", bytes, [&] { hipLaunchKernelGGL(k, g, dim3(1024), tab, 0, C.u, C.ve, C.c.U, C.uidx, C.nrules, C.maxR, C.x, C.d_out, C.hit, rpb); });
     }
+    {
+        const int rpb = 2048;
+        dim3 g(C.c.E, (C.maxR + rpb - 1) / rpb);
+        const bool b1024 = tab > 48 * 1024;
+        CK(hipMemset(C.d_out, 0xFF, C.nd * 8));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int rpb2 : {2048, 8192}) {
+            dim3 g2(C.c.E, (C.maxR + rpb2 - 1) / rpb2);
+            std::vector<float> ts;
+            for (int rep = 0; rep < 5; rep++) {
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 10; i++) hipLaunchKernelGGL((v9_kernel<NANT, (NANT <= 8 ? 4 : 2), 256>), g2, dim3(256), 0, 0, C.uidx, C.nrules, C.maxR, C.d_out, rpb2);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / 10);
+            }
+            std::sort(ts.begin(), ts.end());
+            printf("V9 traffic ceiling (no LDS/sqrt) chunk %-5d       %8.4f ms (min %8.4f)  %7.1f GB/s  frac %.3f\n", rpb2, ts[2], ts[0], bytes / ts[2] / 1e6, bytes / ts[2] / 1e6 / 8000.0);
+        }
+        (void)g; (void)b1024;
+    }
+    {
+        double *qv; CK(hipMalloc(&qv, sizeof(double) * C.c.E * NANT));
+        if (tab <= 8 * 1024) {
+            v2<NANT, 256, 4, false>(C, 0, bytes, qv);
+            v2<NANT, 256, 4, false>(C, 8, bytes, qv);
+            v2<NANT, 256, 4, true>(C, 8, bytes, qv);
+            v2<NANT, 256, 2, true>(C, 8, bytes, qv);
+            v2<NANT, 256, 4, true>(C, 6, bytes, qv);
+            v2<NANT, 256, 4, true>(C, 4, bytes, qv);
+            v2<NANT, 512, 2, true>(C, 4, bytes, qv);
+            v2<NANT, 1024, 1, true>(C, 2, bytes, qv);
+            v2<NANT, 1024, 2, true>(C, 2, bytes, qv);
+        } else if (tab <= 64 * 1024) {
+            v2<NANT, 256, 4, false>(C, 3, bytes, qv);
+            v2<NANT, 256, 4, true>(C, 3, bytes, qv);
+            v2<NANT, 512, 2, true>(C, 3, bytes, qv);
+            v2<NANT, 512, 4, true>(C, 3, bytes, qv);
+            v2<NANT, 1024, 1, true>(C, 1, bytes, qv);
+            v2<NANT, 1024, 2, true>(C, 1, bytes, qv);
+            v2<NANT, 1024, 1, true>(C, 2, bytes, qv);
+            v2<NANT, 1024, 2, false>(C, 2, bytes, qv);
+            v2<NANT, 1024, 2, true>(C, 2, bytes, qv);
+        } else {
+            v2<NANT, 1024, 1, false>(C, 1, bytes, qv);
+            v2<NANT, 1024, 1, true>(C, 1, bytes, qv);
+            v2<NANT, 1024, 2, false>(C, 1, bytes, qv);
+            v2<NANT, 1024, 2, true>(C, 1, bytes, qv);
+            v2<NANT, 512, 2, true>(C, 1, bytes, qv);
+        }
+        unsigned *counter; CK(hipMalloc(&counter, 4));
+        if (tab <= 8 * 1024) {
+            v3<NANT, 256, 4, 1, true>(C, 8, bytes, qv, counter);
+            v3<NANT, 256, 4, 4, true>(C, 8, bytes, qv, counter);
+            v3<NANT, 256, 4, 4, false>(C, 8, bytes, qv, counter);
+            v3<NANT, 256, 4, 8, true>(C, 6, bytes, qv, counter);
+        } else if (tab <= 64 * 1024) {
+            v3<NANT, 1024, 1, 1, false>(C, 1, bytes, qv, counter);
+            v3<NANT, 1024, 1, 1, true>(C, 1, bytes, qv, counter);
+            v3<NANT, 1024, 1, 4, true>(C, 1, bytes, qv, counter);
+            v3<NANT, 1024, 1, 16, true>(C, 1, bytes, qv, counter);
+            v3<NANT, 1024, 1, 4, true>(C, 2, bytes, qv, counter);
+            v3<NANT, 512, 2, 4, true>(C, 3, bytes, qv, counter);
+            v3<NANT, 512, 2, 4, true>(C, 2, bytes, qv, counter);
+            v3<NANT, 256, 4, 4, true>(C, 3, bytes, qv, counter);
+            v3<NANT, 1024, 2, 4, true>(C, 1, bytes, qv, counter);
+        } else {
+            v3<NANT, 1024, 1, 1, false>(C, 1, bytes, qv, counter);
+            v3<NANT, 1024, 1, 1, true>(C, 1, bytes, qv, counter);
+            v3<NANT, 1024, 1, 4, true>(C, 1, bytes, qv, counter);
+            v3<NANT, 512, 2, 1, true>(C, 1, bytes, qv, counter);
+            v3<NANT, 512, 2, 4, true>(C, 1, bytes, qv, counter);
+            v3<NANT, 512, 1, 4, true>(C, 1, bytes, qv, counter);
+        }
+        CK(hipFree(counter));
+        CK(hipFree(qv));
+    }
     const int big = tab > 64 * 1024;
+    if (getenv("RD_V2_ONLY")) return;
     if (!big) {
         const int wmax = tab > 16 * 1024 ? 3 : 8;
         for (int wg : {wmax, wmax > 4 ? 4 : 2}) {
@@ -384,22 +784,20 @@ static void run_cfg(Ctx &C)
             v1<NANT, 256, 2, 4, true, false>(C, wg, 0, bytes);
             v1<NANT, 256, 2, 4, true, true>(C, wg, 0, bytes);
             v1<NANT, 256, 2, 2, true, true>(C, wg, 0, bytes);
-            v1<NANT, 256, 4, 2, true, false>(C, wg, 0, bytes);
-            v1<NANT, 256, 4, 2, true, true>(C, wg, 0, bytes);
-            v1<NANT, 256, 4, 1, true, true>(C, wg, 0, bytes);
-            v1<NANT, 256, 8, 1, true, true>(C, wg, 0, bytes);
+            v1<NANT, 256, 2, 8, true, false>(C, wg, 0, bytes);
         }
         v1<NANT, 512, 2, 4, true, true>(C, tab > 16 * 1024 ? 2 : 4, 0, bytes);
-        v1<NANT, 512, 4, 2, true, true>(C, tab > 16 * 1024 ? 2 : 4, 0, bytes);
-        v1<NANT, 1024, 4, 2, true, true>(C, tab > 16 * 1024 ? 1 : 2, 0, bytes);
+        v1<NANT, 512, 2, 2, true, true>(C, tab > 16 * 1024 ? 2 : 4, 0, bytes);
+        v1<NANT, 1024, 2, 2, true, true>(C, tab > 16 * 1024 ? 1 : 2, 0, bytes);
         v1<NANT, 256, 2, 4, true, true>(C, wmax, 8192, bytes);       // several chunks per environment
+        v1<NANT, 256, 2, 4, true, true>(C, wmax, 16384, bytes);
     } else {
-        for (int chunk : {32768, 65536, 0}) {
+        for (int chunk : {16384, 32768, 65536, 131072}) {
             v1<NANT, 1024, 2, 2, false, false>(C, 1, chunk, bytes);
             v1<NANT, 1024, 2, 2, true, false>(C, 1, chunk, bytes);
-            v1<NANT, 1024, 2, 2, true, true>(C, 1, chunk, bytes);
-            v1<NANT, 1024, 4, 1, true, true>(C, 1, chunk, bytes);
-            v1<NANT, 512, 4, 1, true, true>(C, 1, chunk, bytes);
+            v1<NANT, 1024, 2, 1, true, false>(C, 1, chunk, bytes);
+            v1<NANT, 1024, 2, 1, true, true>(C, 1, chunk, bytes);
+            v1<NANT, 1024, 2, 4, true, false>(C, 1, chunk, bytes);
         }
     }
 }
@@ -411,9 +809,9 @@ int main(int argc, char **argv)
     bool found = false;
     for (const Cfg &c : CFGS) if (!strcmp(c.name, want)) { C.c = c; found = true; }
     if (!found) { fprintf(stderr, "unknown config %s\n", want); return 2; }
-    if (argc > 2) C.c.E = atoi(argv[2]);
+    if (argc > 2 && atoi(argv[2]) > 0) C.c.E = atoi(argv[2]);
     const int nant = C.c.nant, U = C.c.U, E = C.c.E, R = C.c.R;
-    C.maxR = R;
+    C.maxR = R + (argc > 3 ? atoi(argv[3]) : 0);     // pad: production batches keep head-room (maxR = R + 256)
     std::vector<double> u((size_t)nant * U), ve((size_t)nant * U), x((size_t)E * nant);
     uint64_t s = 42;
     for (int k = 0; k < nant; k++) {
@@ -436,6 +834,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&C.bad, 8));
     CK(hipMemcpy(C.u, u.data(), u.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(C.ve, ve.data(), ve.size() * 8, hipMemcpyHostToDevice));
     fill_idx<<<4096, 256>>>(C.uidx, (size_t)E * nant * C.maxR, U, 777);
+    CK(hipMemset(C.d_ref, 0, C.nd * 8));
     std::vector<int32_t> nr(E, R);
     for (int e = 0; e < E; e += 97) nr[e] = R - 1 - (e % 5000);          // some ragged / odd counts
     CK(hipMemcpy(C.nrules, nr.data(), 4 * E, hipMemcpyHostToDevice));
@@ -452,10 +851,11 @@ int main(int argc, char **argv)
     CK(hipMemcpy(C.x, x.data(), x.size() * 8, hipMemcpyHostToDevice));
     CK(hipDeviceSynchronize());
     printf("== %s: nant %d U %d R %d E %d (moved bytes per launch %.3f GB, table %d B)\n", C.c.name, nant, U, R, E, (double)E * R * (2 * nant + 8) / 1e9, 8 * nant * U);
+    const bool sweep = argc > 4 && !strcmp(argv[4], "sweep");
     switch (nant) {
-        case 3: run_cfg<3>(C); break;
-        case 5: run_cfg<5>(C); break;
-        case 16: run_cfg<16>(C); break;
+        case 3: sweep ? run_sweep<3>(C) : run_cfg<3>(C); break;
+        case 5: sweep ? run_sweep<5>(C) : run_cfg<5>(C); break;
+        case 16: sweep ? run_sweep<16>(C) : run_cfg<16>(C); break;
     }
     return 0;
 }
