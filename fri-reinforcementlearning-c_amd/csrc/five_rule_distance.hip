@@ -430,8 +430,9 @@ static int launch_nant(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
         if (e1 != hipSuccess) { set_error("five_hip_rule_distance: cannot reserve %zu B of LDS: %s", tab_bytes, hipGetErrorString(e1)); return FRIRL_HIP_ELAUNCH; }
         return check_launch("five_hip_rule_distance(uidx)");
     }
-    // f64 columns: chunk = one sweep of the workgroup as well (256 threads x 2 rules x UNROLL column sets)
-    if (!make_grid(b, tn.chunk > 0 ? tn.chunk : 2 * FRIRL_BLOCK * UNROLL, g)) { set_error("five_hip_rule_distance: too many work items"); return FRIRL_HIP_EINVAL; }
+    // f64 columns: 1024-rule items for small rule bases, 2048 above (A/B at cfg2: 1024 -> 6.53 TB/s, 2048 -> 6.10, 4096 -> 5.93;
+    // at cfg4: 1024 -> 5.61, 2048 -> 6.20, 4096 -> 6.00, 8192 -> 5.96; tools/ab_rd.py with AB_F64=1)
+    if (!make_grid(b, tn.chunk > 0 ? tn.chunk : (b->maxR <= 16384 + 512 ? 1024 : 2048), g)) { set_error("five_hip_rule_distance: too many work items"); return FRIRL_HIP_EINVAL; }
     if (NANT <= 5 && (tn.unroll || tn.nt >= 0)) {      // tuning hooks (experiments only)
         const int un = tn.unroll ? tn.unroll : UNROLL;
         const int nt = tn.nt >= 0 ? tn.nt : 1;
