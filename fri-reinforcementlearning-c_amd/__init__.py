@@ -44,7 +44,7 @@ class AgentDesc(C.Structure):
                 ("weight_significant", C.c_double), ("skip_rules", C.c_int32), ("p", C.c_int32), ("A", C.c_int32), ("env_kind", C.c_int32),
                 ("max_steps", C.c_int32), ("no_random", C.c_int32), ("grid_len", C.c_int32 * MAX_NANT), ("grid_div", C.c_double * MAX_NANT),
                 ("values_def", C.c_double * MAX_NANT), ("grid_values", C.c_void_p), ("action_ve", C.c_void_p), ("epsilon", C.c_double),
-                ("reward_good_above", C.c_double), ("qdiff_final_tolerance", C.c_double), ("seed", C.c_uint64), ("evaluate", C.c_int32), ("reserved2", C.c_int32), ("env_id_base", C.c_uint64)]
+                ("reward_good_above", C.c_double), ("qdiff_final_tolerance", C.c_double), ("seed", C.c_uint64), ("evaluate", C.c_int32), ("debug_flags", C.c_int32), ("env_id_base", C.c_uint64)]
 
 
 class EnvsDesc(C.Structure):
@@ -331,7 +331,7 @@ class Agent:
 
     def __init__(self, device, nant, grids, grid_div, values_def, action_ve, alpha, gamma, qdiff_pos, qdiff_neg, weight_thr=0.05,
                  skip_rules=1, p=0, env_kind=0, max_steps=1000, epsilon=0.0, no_random=1, seed=0, reward_good_above=0.0,
-                 qdiff_final_tolerance=250.0, env_id_base=0, evaluate=0):
+                 qdiff_final_tolerance=250.0, env_id_base=0, evaluate=0, debug_flags=0):
         import numpy as np
         import torch
         assert len(grids) == nant and all(1 <= len(g) <= MAX_GRID for g in grids)
@@ -351,6 +351,7 @@ class Agent:
             d.values_def[k] = values_def[k] if k < len(values_def) else 0.0
         d.grid_values, d.action_ve = self.grid_values.data_ptr(), self.action_ve.data_ptr()
         d.no_random, d.epsilon, d.seed, d.env_id_base, d.evaluate = no_random, epsilon, seed, env_id_base, evaluate
+        d.debug_flags = debug_flags
         d.reward_good_above, d.qdiff_final_tolerance = reward_good_above, qdiff_final_tolerance
         self.desc, self.nant = d, nant
 

@@ -108,7 +108,7 @@ struct Options {
     int rd_persist;       // compressed rule-distance scan: -1 = by table size, 0 = one workgroup per item, 1 = persistent (FRIRL_HIP_RD_PERSIST)
     int rd_order;         // rule-distance scan item order: 0 = chunk index fastest (shipped), 1 = environment fastest (FRIRL_HIP_RD_ORDER)
     int step_wave;        // episode step: 1 = one wave per environment, 0 = 256 threads, -1 = by shape (FRIRL_HIP_STEP_WAVE)
-    int step_envs;        // episode step: environments per workgroup (wave-per-environment form), 0 = by shape (FRIRL_HIP_STEP_ENVS)
+    int step_track;       // episode step: spread candidates tracked in the fused sweep: 1 / 0, -1 = large rule bases only (FRIRL_HIP_STEP_TRACK)
     int lanes_slices;     // lane groups: rule slices per conclusion, 0 = by shape               (FRIRL_HIP_LANES_SLICES)
     int lanes_wpe;        // lane groups: waves per SIMD, 0 = by shape                           (FRIRL_HIP_LANES_WPE)
     int rollout_group;    // shared-base roll-out: lanes per environment, 0 = by shape           (FRIRL_HIP_ROLLOUT_GROUP)

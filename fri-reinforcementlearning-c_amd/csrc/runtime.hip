@@ -31,7 +31,7 @@ static const OptName k_opts[] = {
     {"rd_persist", "FRIRL_HIP_RD_PERSIST", &Options::rd_persist, -1},
     {"rd_order", "FRIRL_HIP_RD_ORDER", &Options::rd_order, 0},
     {"step_wave", "FRIRL_HIP_STEP_WAVE", &Options::step_wave, -1},
-    {"step_envs", "FRIRL_HIP_STEP_ENVS", &Options::step_envs, 0},
+    {"step_track", "FRIRL_HIP_STEP_TRACK", &Options::step_track, -1},
     {"lanes_slices", "FRIRL_HIP_LANES_SLICES", &Options::lanes_slices, 0},
     {"lanes_wpe", "FRIRL_HIP_LANES_WPE", &Options::lanes_wpe, 0},
     {"rollout_group", "FRIRL_HIP_ROLLOUT_GROUP", &Options::rollout_group, 0},

@@ -25,14 +25,17 @@ struct StepShared {
     int same;
 };
 
+// test hook: frirl_hip_agent.debug_flags bit 0 forces update_rules' second sweep (the candidate path must give the same bits)
+__device__ __forceinline__ bool frirl_no_spread_candidates(const frirl_hip_agent &ag) { return (ag.debug_flags & 1) != 0; }
+
 // frirl_update_sarsa + update_rules (reference src/frirl/frirl_update_sarsa.c:348-385, :22-143).
 // `qp_known`: Q(s',a') already available (fused step: the greedy sweep produced it, identical
 // operands and order -- SURVEY 7(i)); otherwise it is computed by a sweep over ve2.
-template <int NANT, int BLOCK, class COLS, class POW>
+template <int NANT, int BLOCK, bool TRACK = false, class COLS, class POW>
 __device__ int update_sarsa_block(const COLS &cols, const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ base,
                                   int maxR, int32_t *nrules_e, const frirl_hip_agent &ag, StepShared &sh, double reward,
                                   bool qp_known, double qp, int32_t *fus_e, double *rant_e, BlockRed<BLOCK> &red,
-                                  const QResult *rn_known, uint16_t *uidx_e, POW p)
+                                  const QResult *rn_known, uint16_t *uidx_e, POW p, SpreadCand *slot)
 {
     const int R = *nrules_e;
     double q1[NANT], q2[NANT];
@@ -44,7 +47,7 @@ __device__ int update_sarsa_block(const COLS &cols, const double *__restrict__ u
         const QResult rp = sweep_q<NANT, BLOCK>(cols, qcol, R, q2, p, red);
         qp = (rp.hit != FRIRL_HIP_NO_HIT) ? qcol[rp.hit] : rp.vagc / rp.ws;
     }
-    const QResult rn = rn_known ? *rn_known : sweep_q<NANT, BLOCK>(cols, qcol, R, q1, p, red);    // :357  Q(s,a)
+    const QResult rn = rn_known ? *rn_known : sweep_q<NANT, BLOCK, TRACK>(cols, qcol, R, q1, p, red, ag.weight_significant, slot);    // :357  Q(s,a)
     const double qnow = (rn.hit != FRIRL_HIP_NO_HIT) ? qcol[rn.hit] : rn.vagc / rn.ws;
     const double qdiff = ag.alpha * (reward + ag.gamma * qp - qnow);        // :358
     int fus = *fus_e;
@@ -98,7 +101,10 @@ __device__ int update_sarsa_block(const COLS &cols, const double *__restrict__ u
     } else {
         if (ag.skip_rules == 0) fus = 0;                                    // :70-73
         const int r_skip = fus ? R - 1 : -1;                                // :76,124-126: the just-inserted rule keeps its Q
-        sweep_update<NANT, BLOCK>(cols, qcol, R, q1, p, rn.ws, qnow, qdiff, ag.weight_significant, r_skip);   // K6+K7
+        // K6+K7: from the candidates tracked during the Q(s,a) sweep when possible (no second pass over the slab), else the sweep
+        const bool from_cand = TRACK && rn.tracked && rn.hit == FRIRL_HIP_NO_HIT && !frirl_no_spread_candidates(ag) &&
+                               spread_from_candidates<BLOCK>(slot[threadIdx.x], qcol, rn.ws, qnow, qdiff, ag.weight_significant, r_skip, red);
+        if (!from_cand) sweep_update<NANT, BLOCK>(cols, qcol, R, q1, p, rn.ws, qnow, qdiff, ag.weight_significant, r_skip);
         status = FRIRL_HIP_UPD_SPREAD;
     }
     if (threadIdx.x == 0) *fus_e = fus;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(BLOCK) void update_sarsa_kernel(const double *__res
     uint16_t *uidx_e = uidx ? uidx + (size_t)e * NANT * maxR : nullptr;
     const auto cols = ColsSel<IDX>::make(base, uidx_e, tab_s, maxR, U);
     const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, reward[e], false, 0.0, ev.fus + e, rant_e, red, nullptr, uidx_e,
-                                                   ag.p > 0 ? ag.p : NANT);
+                                                   ag.p > 0 ? ag.p : NANT, nullptr);
     if (threadIdx.x == 0 && ev.status) ev.status[e] = st;
 }
 
@@ -239,7 +245,9 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 // for the others -- without the bound the 5-antecedent, many-action variants sit just above 128 and lose a wave
 constexpr int step_min_waves(int nant, int amax) { return (nant <= 3 && amax <= 4) ? 6 : 4; }
 
-template <int NANT, int AMAX, int BLOCK, bool IDX, bool PN>
+// TRACK: the candidates of update_rules' write-back are collected during the fused sweep (sweeps.h: SpreadCand) -- for LARGE rule
+// bases, where the second sweep it saves is a second pass over HBM; small slabs are re-read from L2 and the plain form is faster.
+template <int NANT, int AMAX, int BLOCK, bool IDX, bool PN, bool TRACK>
 __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                               double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules,
                                                               int maxR, const frirl_hip_agent ag, const frirl_hip_envs ev)
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     __shared__ StepShared sh;
     __shared__ BlockRed<BLOCK> red;
     __shared__ GbaScratch<AMAX, BLOCK> gs;
+    __shared__ SpreadCand cand_s[TRACK ? BLOCK : 1];       // one slot per lane: candidates of update_rules' write-back (sweeps.h)
     if (IDX) for (int i = threadIdx.x; i < NANT * U; i += BLOCK) tab_s[i] = ve[i];
     if (threadIdx.x == 0) {
         double s[FRIRL_HIP_MAX_NANT], q[FRIRL_HIP_MAX_NANT];
@@ -282,8 +291,8 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     const auto pw = PowSel<PN, NANT>::make(ag.p > 0 ? ag.p : NANT);
     QResult rn;
     // one pass over the slab: greedy action for s' (:148) AND Q(s,a) of the pending update (frirl_update_sarsa.c:357)
-    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn)
-                              : sweep_gba_q<NANT, AMAX, BLOCK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn);
+    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn, ag.weight_significant, cand_s)
+                              : sweep_gba_q<NANT, AMAX, BLOCK, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
     if (threadIdx.x == 0) {
         const int chosen = e_greedy(ag, ap, (uint32_t)e, ev.episode ? (uint32_t)ev.episode[e] : 0u, (uint32_t)ev.ep_steps[e] + 1u);
         gs.best = chosen;
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
     int st = FRIRL_HIP_UPD_INACTIVE;
     if (!ag.evaluate)                                                                                 // :155 (reduction_state == 0)
-        st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn, uidx_e, pw);  // :159
+        st = update_sarsa_block<NANT, BLOCK, TRACK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn, uidx_e, pw, cand_s);  // :159
     if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
     if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.cur_q_ant[threadIdx.x];    // :166-168
     if (threadIdx.x == 0) {
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
         __syncthreads();
         const double qp = gs.actconc[gs.best];
         int st = FRIRL_HIP_UPD_INACTIVE;
-        if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr, p);
+        if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr, p, nullptr);
         __syncthreads();
         if (st == FRIRL_HIP_UPD_INSERTED && threadIdx.x < NANT) {
             if (rant_e) rant_e[(size_t)threadIdx.x * maxR + (nrules_s - 1)] = sh.rant[threadIdx.x];
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) void mirror_step_kernel(const double *__rest
     if (threadIdx.x < NANT) out->cur_q_ant[threadIdx.x] = sh.cur_q_ant[threadIdx.x];
     const double qp = gs.actconc[ap];
     const int R_before = nrules[0];
-    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, rb, maxR, nrules, ag, sh, in.reward, true, qp, &fus_s, rant_store, red, &rn, nullptr, p);
+    const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, rb, maxR, nrules, ag, sh, in.reward, true, qp, &fus_s, rant_store, red, &rn, nullptr, p, nullptr);
     __syncthreads();
     const int R = (st == FRIRL_HIP_UPD_INSERTED) ? R_before + 1 : R_before;
     for (int r = threadIdx.x; r < R; r += BLOCK) rconc_out[r] = rb[(size_t)NANT * maxR + r];
@@ -609,15 +618,21 @@ static void launch_episode_v(const frirl_hip_tables *t, const frirl_hip_rulebase
     const bool idx = frirl::use_uidx(t, b) && (BLOCK == 256 || sizeof(double) * t->nant * (size_t)t->U <= 4096);
     const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
     const bool pn = ag->p <= 0 || ag->p == N;                     // the Shepard power is the default nant: straight-line power (PowC<N>)
-#define EP_GO(KERNEL, IDX_, PN_, DYN)                                                                                                            \
-    hipLaunchKernelGGL((frirl::KERNEL<N, AMAX, BLOCK, IDX_, PN_>), dim3(b->E), dim3(BLOCK), DYN, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
+    // spread candidates tracked in the fused sweep: only where the second sweep would be a second pass over HBM (large slabs)
+    const int st_opt = frirl_host::opts().step_track;
+    const bool track = st_opt == 1 || (st_opt < 0 && b->maxR > 16384 + 512);
+#define EP_GO(KERNEL, DYN, ...)                                                                                                                  \
+    hipLaunchKernelGGL((frirl::KERNEL<N, AMAX, BLOCK, __VA_ARGS__>), dim3(b->E), dim3(BLOCK), DYN, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
                        b->maxR, *ag, *ev)
     if (BEGIN) {
-        if (idx) { if (pn) EP_GO(episode_begin_kernel, true, true, tab); else EP_GO(episode_begin_kernel, true, false, tab); }
-        else { if (pn) EP_GO(episode_begin_kernel, false, true, 0); else EP_GO(episode_begin_kernel, false, false, 0); }
+        if (idx) { if (pn) EP_GO(episode_begin_kernel, tab, true, true); else EP_GO(episode_begin_kernel, tab, true, false); }
+        else { if (pn) EP_GO(episode_begin_kernel, 0, false, true); else EP_GO(episode_begin_kernel, 0, false, false); }
+    } else if (track) {
+        if (idx) { if (pn) EP_GO(episode_step_kernel, tab, true, true, true); else EP_GO(episode_step_kernel, tab, true, false, true); }
+        else { if (pn) EP_GO(episode_step_kernel, 0, false, true, true); else EP_GO(episode_step_kernel, 0, false, false, true); }
     } else {
-        if (idx) { if (pn) EP_GO(episode_step_kernel, true, true, tab); else EP_GO(episode_step_kernel, true, false, tab); }
-        else { if (pn) EP_GO(episode_step_kernel, false, true, 0); else EP_GO(episode_step_kernel, false, false, 0); }
+        if (idx) { if (pn) EP_GO(episode_step_kernel, tab, true, true, false); else EP_GO(episode_step_kernel, tab, true, false, false); }
+        else { if (pn) EP_GO(episode_step_kernel, 0, false, true, false); else EP_GO(episode_step_kernel, 0, false, false, false); }
     }
 #undef EP_GO
 }

@@ -221,40 +221,107 @@ __device__ __forceinline__ void sq_dist2(const COLS &cols, int r, const double (
     }
 }
 
+// Candidates for update_rules' masked write-back (frirl_update_sarsa.c:89-120): rconc[r] changes only where the normalised
+// Shepard weight wi_r / ws exceeds the threshold (0.05 => at most 19 rules of the whole rule base), but ws is known only
+// after the sweep -- the reference (and round 1) therefore sweep the rule base a second time.  Instead every lane keeps, during
+// the Q(s,a) sweep, the two largest wi it has seen (+ the value of the third) in a slot of its own in LDS (registers are the
+// scarce resource of these sweeps; kept in VGPRs the five values spilled the hot loop: 8x slower): a rule that finally qualifies satisfies
+// wi > thr * ws >= thr * (any earlier partial sum of the WAVE), so the hot loop only compares wi with a wave-uniform bound T and
+// the slot is touched on the rare iterations where some lane passes; T is refreshed there from the wave's running sums (a bound
+// from the LANE's own sum is useless: Shepard weights are heavy-tailed, some lane of 64 passes it on ~90 % of the iterations
+// -- measured 3x slower).  After the
+// reduction the <= 2 candidates per lane are filtered with the exact test of the second sweep (wi * (1/ws) > thr, same
+// operands, same bits); if a lane's THIRD value would qualify too (more than two qualifying rules in one lane) the
+// workgroup falls back to the second sweep.  Saves one pass over the slab for ~40 % of the updates at the BASELINE shapes.
+// the lane-local pre-filter compares against a slightly smaller threshold, so that the roundings of wi * (1 / ws) in the exact
+// test can never let a rule qualify that the pre-filter skipped
+static constexpr double SPREAD_PREFILTER_SLACK = 1.0 - 1.0 / 1048576.0;
+
+struct SpreadCand {
+    double w1, w2, w3;      // largest, second, third wi of this lane (0 = none)
+    unsigned r1, r2;        // their rule indices
+    __device__ __forceinline__ void clear() { w1 = w2 = w3 = 0.0; r1 = r2 = FRIRL_HIP_NO_HIT; }
+    __device__ __forceinline__ void offer(double wi, unsigned r)
+    {
+        if (wi > w1) { w3 = w2; w2 = w1; r2 = r1; w1 = wi; r1 = r; }
+        else if (wi > w2) { w3 = w2; w2 = wi; r2 = r; }
+        else if (wi > w3) w3 = wi;
+    }
+};
+
+// One rule's weight against the wave-uniform bound T (see above); `run` = this lane's running sum of the same sweep.
+// Every lane of the wave must call it together (the refresh is a wave reduction).
+// a wave-uniform double kept in scalar registers (the sweeps are VGPR-bound: every vector register spilled costs scratch traffic
+// in the hot loop)
+__device__ __forceinline__ double wave_uniform(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ void spread_track(SpreadCand *slots, double &T, double thr, double w0, double w1, unsigned r, double run)
+{
+    const bool p0 = w0 > T, p1 = w1 > T;      // w = 0 for exact hits / rules past the end: never passes
+    if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {       // wave-uniform, and rare once T is meaningful
+        SpreadCand *slot = slots + threadIdx.x;
+        if (p0) slot->offer(w0, r);
+        if (p1) slot->offer(w1, r + 1u);
+        T = wave_uniform(thr * wave_sum_f64(run));
+    }
+}
+
+// trip count of a lane-strided sweep over R rules rounded up so that all 64 lanes of a wave leave the loop together
+__device__ __forceinline__ int wave_uniform_limit(int R) { return ((R + 2 * FRIRL_WAVE - 1) / (2 * FRIRL_WAVE)) * (2 * FRIRL_WAVE); }
+
 struct QResult {
     unsigned hit;   // lowest rule index with distance exactly 0, or FRIRL_HIP_NO_HIT
     double vagc;    // sum wi * Q   (valid when hit == NO_HIT)
     double ws;      // sum wi
+    bool tracked;   // the lanes' SpreadCand slots hold the candidates of this sweep
 };
 
 // FIVE_vag_concl's sweep (reference src/five/FIVEVagConcl.c:64-351 live path): distances, first
 // exact hit, Shepard sums wi = 1/d^p, vagc = sum wi*Q, ws = sum wi (:224-235).  All threads return
 // the same QResult.
-template <int NANT, int BLOCK, class COLS, class POW>
-__device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&q)[NANT], POW p, BlockRed<BLOCK> &red)
+template <int NANT, int BLOCK, bool TRACK = false, class COLS, class POW>
+__device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&q)[NANT], POW p, BlockRed<BLOCK> &red, double track_thr = 0.0,
+                           SpreadCand *slot = nullptr)
 {
     unsigned best = FRIRL_HIP_NO_HIT;
     double sv = 0.0, sw = 0.0;
-    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
-        double a0, a1;
-        sq_dist2<NANT>(cols, r, q, a0, a1);
-        const double2 c = load_col2(qcol + r);
-        if (a0 == 0.0) best = min(best, (unsigned)r);
-        else {
-            const double wi = shepard_w(a0, p);
-            sv = __fma_rn(wi, c.x, sv);
-            sw = sw + wi;
-        }
-        if (r + 1 < R) {
-            if (a1 == 0.0) best = min(best, (unsigned)(r + 1));
+    QResult res;
+    res.tracked = TRACK;
+    if (TRACK) slot[threadIdx.x].clear();          // `slot` = the workgroup's slot array, one entry per lane
+    track_thr = wave_uniform(track_thr * SPREAD_PREFILTER_SLACK);
+    double T = 0.0;
+    // tracked form: wave-uniform trip count (spread_track is a wave-level operation); lanes past R idle through their last turn
+    const int r_lim = TRACK ? wave_uniform_limit(R) : R;
+    for (int r = 2 * (int)threadIdx.x; r < r_lim; r += 2 * BLOCK) {
+        double tw0 = 0.0, tw1 = 0.0;
+        if (!TRACK || r < R) {
+            double a0, a1;
+            sq_dist2<NANT>(cols, r, q, a0, a1);
+            const double2 c = load_col2(qcol + r);
+            if (a0 == 0.0) best = min(best, (unsigned)r);
             else {
-                const double wi = shepard_w(a1, p);
-                sv = __fma_rn(wi, c.y, sv);
+                const double wi = shepard_w(a0, p);
+                sv = __fma_rn(wi, c.x, sv);
                 sw = sw + wi;
+                tw0 = wi;
+            }
+            if (r + 1 < R) {
+                if (a1 == 0.0) best = min(best, (unsigned)(r + 1));
+                else {
+                    const double wi = shepard_w(a1, p);
+                    sv = __fma_rn(wi, c.y, sv);
+                    sw = sw + wi;
+                    tw1 = wi;
+                }
             }
         }
+        if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, sw);
     }
-    QResult res;
     res.hit = blk_min<BLOCK>(best, red);
     res.vagc = blk_sum<BLOCK>(sv, red);
     res.ws = blk_sum<BLOCK>(sw, red);
@@ -296,6 +363,26 @@ __device__ void sweep_update(const COLS &cols, double *__restrict__ qcol, int R,
         if (w0 > threshold && r != r_skip) { const double t = qdiff * w0; qcol[r] = qnow + t; }
         if (r + 1 < R && w1 > threshold && r + 1 != r_skip) { const double t = qdiff * w1; qcol[r + 1] = qnow + t; }
     }
+}
+
+// The same write-back from the per-lane candidates of a tracked Q(s,a) sweep (SpreadCand); false = some lane holds more
+// than two qualifying rules: nothing was written, the caller runs sweep_update.
+template <int BLOCK>
+__device__ bool spread_from_candidates(const SpreadCand &cd, double *__restrict__ qcol, double ws, double qnow, double qdiff, double threshold, int r_skip,
+                                       BlockRed<BLOCK> &red)
+{
+    const double iws = 1.0 / ws;
+    const unsigned ovf = (cd.w3 * iws > threshold) ? 0u : 1u;
+    if (blk_min<BLOCK>(ovf, red) == 0u) return false;
+    if (cd.r1 != FRIRL_HIP_NO_HIT) {
+        const double w = cd.w1 * iws;
+        if (w > threshold && (int)cd.r1 != r_skip) { const double t = qdiff * w; qcol[cd.r1] = qnow + t; }
+    }
+    if (cd.r2 != FRIRL_HIP_NO_HIT) {
+        const double w = cd.w2 * iws;
+        if (w > threshold && (int)cd.r2 != r_skip) { const double t = qdiff * w; qcol[cd.r2] = qnow + t; }
+    }
+    return true;
 }
 
 // frirl_get_best_action's sweep (reference src/frirl/frirl_get_best_action.c:31-341): the state
@@ -385,11 +472,15 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
 // (frirl_episode.c:148 -> :159), so one pass over the slab serves both: 8*(nant+1) B per rule and step
 // instead of twice that.  Per-lane accumulation order and the reduction tree are those of the two separate
 // sweeps, so every result is bit-identical to running them one after the other.
-template <int NANT, int AMAX, int BLOCK, class COLS, class POW>
+template <int NANT, int AMAX, int BLOCK, bool TRACK = false, class COLS, class POW>
 __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
-                           const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres)
+                           const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres, double track_thr = 0.0,
+                           SpreadCand *slot = nullptr)
 {
     constexpr int NS = NANT - 1;
+    if (TRACK) slot[threadIdx.x].clear();          // `slot` = the workgroup's slot array, one entry per lane
+    qres.tracked = TRACK;
+    track_thr = wave_uniform(track_thr * SPREAD_PREFILTER_SLACK);
     double sv[AMAX], sw[AMAX], av[AMAX];
     unsigned sh[AMAX];
 #pragma unroll
@@ -408,22 +499,29 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
             nc = load_col2(qcol + r0);
         }
     }
-    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
-        typename COLS::raw_t raw[NANT];
-#pragma unroll
-        for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
-        const double2 c = nc;
-        if (r + 2 * BLOCK < R) {
-#pragma unroll
-            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * BLOCK);
-            nc = load_col2(qcol + r + 2 * BLOCK);
-        }
-        double2 v[NANT];
-#pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
+    double T = 0.0;
+    // tracked form: wave-uniform trip count, because spread_track is a wave-level operation with ONE call site that every
+    // lane of the wave reaches together; lanes whose last pair lies past R skip the arithmetic of that turn
+    const int r_lim = TRACK ? wave_uniform_limit(R) : R;
+    for (int r = 2 * (int)threadIdx.x; r < r_lim; r += 2 * BLOCK) {
+        const bool live = !TRACK || r < R;
         const bool second = (r + 1 < R);
-        // (1) Q(s,a): full distance to the pending antecedents
-        {
+        double2 v[NANT];
+        double2 c = {0.0, 0.0};
+        double tw0 = 0.0, tw1 = 0.0;
+        if (live) {
+            typename COLS::raw_t raw[NANT];
+#pragma unroll
+            for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
+            c = nc;
+            if (r + 2 * BLOCK < R) {
+#pragma unroll
+                for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * BLOCK);
+                nc = load_col2(qcol + r + 2 * BLOCK);
+            }
+#pragma unroll
+            for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
+            // (1) Q(s,a): full distance to the pending antecedents
             double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
             double a0 = d0 * d0, a1 = d1 * d1;
 #pragma unroll
@@ -432,34 +530,37 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
+            else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; tw0 = wi; }
             if (second) {
                 if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; }
+                else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; tw1 = wi; }
             }
         }
-        // (2) greedy sweep for the new state: state part once, then every action
-        double s0, s1;
-        {
-            double d0 = qs[0] - v[0].x, d1 = qs[0] - v[0].y;
-            s0 = d0 * d0; s1 = d1 * d1;
+        if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);
+        if (live) {
+            // (2) greedy sweep for the new state: state part once, then every action
+            double s0, s1;
+            {
+                double d0 = qs[0] - v[0].x, d1 = qs[0] - v[0].y;
+                s0 = d0 * d0; s1 = d1 * d1;
 #pragma unroll
-            for (int k = 1; k < NS; k++) {
-                d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
-                s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
+                for (int k = 1; k < NS; k++) {
+                    d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
+                    s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
+                }
             }
-        }
-        const double2 va = v[NS];
+            const double2 va = v[NS];
 #pragma unroll
-        for (int a = 0; a < AMAX; a++) {
-            if (a < A) {
-                const double e0 = av[a] - va.x, e1 = av[a] - va.y;
-                const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);        // squared distances
-                if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
-                else { const double wi = shepard_w(d0, p); sv[a] = __fma_rn(wi, c.x, sv[a]); sw[a] = sw[a] + wi; }
-                if (second) {
-                    if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
-                    else { const double wi = shepard_w(d1, p); sv[a] = __fma_rn(wi, c.y, sv[a]); sw[a] = sw[a] + wi; }
+            for (int a = 0; a < AMAX; a++) {
+                if (a < A) {
+                    const double e0 = av[a] - va.x, e1 = av[a] - va.y;
+                    const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);        // squared distances
+                    if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
+                    else { const double wi = shepard_w(d0, p); sv[a] = __fma_rn(wi, c.x, sv[a]); sw[a] = sw[a] + wi; }
+                    if (second) {
+                        if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
+                        else { const double wi = shepard_w(d1, p); sv[a] = __fma_rn(wi, c.y, sv[a]); sw[a] = sw[a] + wi; }
+                    }
                 }
             }
         }
@@ -501,12 +602,15 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
 // columns almost simultaneously, so HBM still sees each rule once (L1/L2 absorb the repeats) while the
 // register footprint drops to AG accumulator pairs.  The optional Q(s,a) sums of the fused episode step are
 // spread over the waves by iteration.  Sums per action are one wave butterfly (deterministic).
-template <int NANT, int AG, int AMAX, int BLOCK, bool WITH_Q, class COLS, class POW>
+template <int NANT, int AG, int AMAX, int BLOCK, bool WITH_Q, bool TRACK = false, class COLS, class POW>
 __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
-                              const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult *qres)
+                              const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult *qres, double track_thr = 0.0,
+                              SpreadCand *slot = nullptr)
 {
     constexpr int NS = NANT - 1;
     constexpr int WAVES = BLOCK / FRIRL_WAVE;
+    if (TRACK) slot[threadIdx.x].clear();          // `slot` = the workgroup's slot array, one entry per lane
+    track_thr = wave_uniform(track_thr * SPREAD_PREFILTER_SLACK);
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
     const int ag = (A + WAVES - 1) / WAVES;            // actions per wave (<= AG)
     const int a_begin = wave * ag;
@@ -527,56 +631,68 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
         for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, 2 * lane);
         nc = load_col2(qcol + 2 * lane);
     }
-    for (int r = 2 * lane; r < R; r += 2 * FRIRL_WAVE, it++) {
-        typename COLS::raw_t raw[NANT];
-#pragma unroll
-        for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
-        const double2 c = nc;
-        if (r + 2 * FRIRL_WAVE < R) {
-#pragma unroll
-            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * FRIRL_WAVE);
-            nc = load_col2(qcol + r + 2 * FRIRL_WAVE);
-        }
-        double2 v[NANT];
-#pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
+    double T = 0.0;
+    const int r_lim = (WITH_Q && TRACK) ? wave_uniform_limit(R) : R;      // see sweep_gba_q
+    for (int r = 2 * lane; r < r_lim; r += 2 * FRIRL_WAVE, it++) {
+        const bool live = !(WITH_Q && TRACK) || r < R;
         const bool second = (r + 1 < R);
-        if (WITH_Q && (it % WAVES) == wave) {
-            double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
-            double a0 = d0 * d0, a1 = d1 * d1;
+        double2 v[NANT];
+        double2 c = {0.0, 0.0};
+        if (live) {
+            typename COLS::raw_t raw[NANT];
 #pragma unroll
-            for (int k = 1; k < NANT; k++) {
-                d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
-                a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
+            for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
+            c = nc;
+            if (r + 2 * FRIRL_WAVE < R) {
+#pragma unroll
+                for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * FRIRL_WAVE);
+                nc = load_col2(qcol + r + 2 * FRIRL_WAVE);
             }
-            if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
-            if (second) {
-                if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; }
-            }
+#pragma unroll
+            for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
         }
-        double s0, s1;
-        {
-            double d0 = qs[0] - v[0].x, d1 = qs[0] - v[0].y;
-            s0 = d0 * d0; s1 = d1 * d1;
+        if (WITH_Q && (it % WAVES) == wave) {           // wave-uniform: the Q(s,a) sums are spread over the waves by iteration
+            double tw0 = 0.0, tw1 = 0.0;
+            if (live) {
+                double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
+                double a0 = d0 * d0, a1 = d1 * d1;
 #pragma unroll
-            for (int k = 1; k < NS; k++) {
-                d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
-                s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
-            }
-        }
-        const double2 va = v[NS];
-#pragma unroll
-        for (int j = 0; j < AG; j++) {
-            if (j < na) {
-                const double e0 = av[j] - va.x, e1 = av[j] - va.y;
-                const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);
-                if (d0 == 0.0) sh[j] = min(sh[j], (unsigned)r);
-                else { const double wi = shepard_w(d0, p); sv[j] = __fma_rn(wi, c.x, sv[j]); sw[j] = sw[j] + wi; }
+                for (int k = 1; k < NANT; k++) {
+                    d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
+                    a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
+                }
+                if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
+                else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; tw0 = wi; }
                 if (second) {
-                    if (d1 == 0.0) sh[j] = min(sh[j], (unsigned)(r + 1));
-                    else { const double wi = shepard_w(d1, p); sv[j] = __fma_rn(wi, c.y, sv[j]); sw[j] = sw[j] + wi; }
+                    if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
+                    else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; tw1 = wi; }
+                }
+            }
+            if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);
+        }
+        if (live) {
+            double s0, s1;
+            {
+                double d0 = qs[0] - v[0].x, d1 = qs[0] - v[0].y;
+                s0 = d0 * d0; s1 = d1 * d1;
+#pragma unroll
+                for (int k = 1; k < NS; k++) {
+                    d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
+                    s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
+                }
+            }
+            const double2 va = v[NS];
+#pragma unroll
+            for (int j = 0; j < AG; j++) {
+                if (j < na) {
+                    const double e0 = av[j] - va.x, e1 = av[j] - va.y;
+                    const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);
+                    if (d0 == 0.0) sh[j] = min(sh[j], (unsigned)r);
+                    else { const double wi = shepard_w(d0, p); sv[j] = __fma_rn(wi, c.x, sv[j]); sw[j] = sw[j] + wi; }
+                    if (second) {
+                        if (d1 == 0.0) sh[j] = min(sh[j], (unsigned)(r + 1));
+                        else { const double wi = shepard_w(d1, p); sv[j] = __fma_rn(wi, c.y, sv[j]); sw[j] = sw[j] + wi; }
+                    }
                 }
             }
         }
@@ -593,6 +709,7 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
         qres->hit = blk_min<BLOCK>(qbest, red);
         qres->vagc = blk_sum<BLOCK>(qv, red);
         qres->ws = blk_sum<BLOCK>(qw, red);
+        qres->tracked = TRACK;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

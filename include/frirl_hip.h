@@ -97,7 +97,7 @@ int frirl_hip_device_count(void);                 /* number of visible gfx950 de
 int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, int64_t *hbm_bytes);
 
 /* Experiment / test switches by name: "no_uidx" (1 = ignore the 16-bit index mirror), "rd_unroll", "rd_chunk", "rd_nt",
- * "rd_persist", "rd_order", "step_wave", "step_envs", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices".  Their defaults
+ * "rd_persist", "rd_order", "step_wave", "step_track", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices".  Their defaults
  * (the shipped configuration) are read ONCE from the matching FRIRL_HIP_<NAME> environment variable, never per launch;
  * results do not depend on any of them (only the kernel variant / launch shape does). */
 int frirl_hip_set_option(const char *name, int value);
@@ -168,7 +168,8 @@ typedef struct frirl_hip_agent {
     uint64_t seed;                             /* base seed of the per-environment counter-based RNG       */
     int32_t evaluate;                          /* 1 = policy roll-out only: no SARSA update (frirl_desc.reduction_state == 1,
                                                   frirl_episode.c:155; frirl_test_run / the reduction replays)        */
-    int32_t reserved2;
+    int32_t debug_flags;                       /* 0; bit 0 (tests only): update_rules always re-sweeps the rule base instead of using the
+                                                  candidates tracked during the Q(s,a) sweep -- both give the same bits */
     uint64_t env_id_base;                      /* global id of environment 0 of this batch: RNG streams are keyed by the
                                                   GLOBAL environment id, so trajectories do not depend on the sharding */
 } frirl_hip_agent;

@@ -203,3 +203,41 @@ def test_fused_episode_steps_follow_oracle(env, n_episodes):
         assert rel(rb[:, nant, : f.R], f.rconc[None, : f.R]).max() <= 1e-9
         assert (envs.rant.cpu().numpy()[:, :, : f.R] == f.rant[: f.R].T[None]).all()
         assert (envs.fus.cpu().numpy() == int(fr.fus)).all()
+
+
+@pytest.mark.parametrize("env,E,R", [("mountaincar", 300, 3000), ("acrobot", 300, 6000), ("cartpole", 64, 5000), ("acrobot", 40, 1500)])
+def test_spread_candidates_equal_the_second_sweep(env, E, R, hip_option):
+    """update_rules' masked write-back (frirl_update_sarsa.c:89-120) from the candidates tracked during the Q(s,a) sweep must
+    give the bits of the reference-shaped second sweep (agent.debug_flags bit 0 forces it) -- every step kernel form
+    (256 threads / one wave per environment / action-parallel waves), including lanes that hold MORE than two qualifying
+    rules (near-duplicate rules planted in one lane's slots: the workgroup must fall back to the sweep)."""
+    import torch
+    dev0 = torch.device("cuda", 0)
+    hip_option("step_track", 1)          # by default only rule bases > 16 K rules use the candidates
+    outs = []
+    for flags in (0, 1):
+        prob, agent, envs = frirl_amd.demo_batch(env, E, R, R + 256, dev0, seed=13)
+        agent.desc.debug_flags = flags
+        nant = prob.nant
+        # environments 0..7: rules 10, 11, 138, 139, 522, 523 become near-duplicates of one point next to the start state, so that
+        # all of them carry a large Shepard weight for the first updates (slots of ONE lane in both the 64- and 256-thread kernels)
+        d = frirl_amd.demo_describe(env)
+        for e in range(8):
+            for j, r in enumerate((10, 11, 138, 139, 522, 523)):
+                for k in range(nant):
+                    base_idx = int(np.argmin(np.abs(d["u"][k] - (d["values_def"][k] if k < nant - 1 else d["grids"][k][0]))))
+                    idx = min(max(base_idx + (1 if (k == (j % (nant - 1))) else 0) + (1 if k == 0 else 0), 0), prob.U - 1)
+                    prob.uidx[e, k, r] = idx
+                    prob.rb[e, k, r] = prob.ve[k, idx]
+                    envs.rant[e, k, r] = prob.u[k, idx]
+                prob.rb[e, nant, r] = 100.0 + j
+        frirl_amd.episode_begin(prob, agent, envs)
+        seen = torch.zeros(6, dtype=torch.int64, device=dev0)
+        for _ in range(6):
+            frirl_amd.episode_steps(prob, agent, envs, 1)
+            seen += torch.bincount(envs.status.long(), minlength=6)
+        torch.cuda.synchronize()
+        outs.append((prob.rb.clone(), prob.nrules.clone(), envs.states.clone(), envs.q_ant.clone(), envs.fus.clone(), seen))
+    for i, (a, b) in enumerate(zip(outs[0][:5], outs[1][:5])):
+        assert (a == b).all(), i
+    assert (outs[0][5] == outs[1][5]).all() and int(outs[0][5][frirl_amd.UPD_SPREAD]) > 0, outs[0][5].tolist()
