@@ -123,6 +123,14 @@ SIGNATURES = {
     "frirl_hip_batch_save_rulebases": (C.c_int, [C.c_void_p, C.c_char_p]),
     "frirl_hip_batch_load_rulebases": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "frirl_hip_batch_reduce": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, C.c_double, C.c_int, C.POINTER(ReduceResult)]),
+    # several GPUs from plain C (one batch + host thread per device, RCCL all-reduce of the report)
+    "frirl_hip_shard": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "frirl_hip_multi_create": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int32]),
+    "frirl_hip_multi_destroy": (None, [C.c_void_p]),
+    "frirl_hip_multi_train": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "frirl_hip_multi_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "frirl_hip_multi_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "frirl_hip_multi_get_rulebase": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), _DP, _DP]),
     # single rule base, host pointers (what the ANSI-C drop-in library calls)
     "five_hip_mirror_create": (C.c_void_p, [C.c_int32, C.c_int32, _DP, _DP, C.c_int32, C.c_int32]),
     "five_hip_mirror_destroy": (None, [C.c_void_p]),

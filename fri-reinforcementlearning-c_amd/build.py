@@ -51,7 +51,7 @@ def build_hip(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc failed for " + ", ".join(failed))
     objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in srcs]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print("+", " ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -13,6 +13,7 @@ using namespace frirl_host;
 
 struct frirl_hip_batch {
     int32_t nant, U, E, maxR;
+    int device;                  // every entry point switches the calling thread to it (batches of several devices in one process)
     hipStream_t s;
     double *d_u, *d_ve, *d_rb, *d_rant, *d_grid, *d_ave, *d_states, *d_q_ant, *d_ep_reward, *d_start, *d_prev_reward, *d_prev_rconc, *d_tmp;
     uint16_t *d_uidx;            // 16-bit universe-index mirror of the antecedents (compressed scans, lane-group index store)
@@ -65,6 +66,7 @@ __global__ void count_running_kernel(const int32_t *__restrict__ done, int E, in
 extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
 {
     if (!b) return;
+    (void)hipSetDevice(b->device);
     if (b->s) (void)hipStreamSynchronize(b->s);
     void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
                     b->d_prev_rconc, b->d_tmp, b->d_nrules, b->d_fus, b->d_done, b->d_ep_steps, b->d_status, b->d_episode, b->d_prev_nrules,
@@ -78,8 +80,10 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
 {
     if (!d || !d->u || !d->ve || !d->agent.grid_values || !d->agent.action_ve || !d->rant0 || !d->rconc0) { set_error("frirl_hip_batch_create: NULL pointer"); return nullptr; }
     if (d->nant < 2 || d->nant > 9 || d->U < 2 || d->E < 1 || d->maxR < 2 || d->R0 < 1 || d->R0 > d->maxR || d->agent.A < 1 || d->agent.A > FRIRL_HIP_MAX_ACTIONS) { set_error("frirl_hip_batch_create: bad sizes"); return nullptr; }
+    if (d->device_select == 1 && hipSetDevice(d->device) != hipSuccess) { set_error("frirl_hip_batch_create: hipSetDevice(%d) failed", d->device); (void)hipGetLastError(); return nullptr; }
     if (check_device()) return nullptr;
     frirl_hip_batch *b = new frirl_hip_batch();
+    if (hipGetDevice(&b->device) != hipSuccess) b->device = 0;
     b->nant = d->nant; b->U = d->U; b->E = d->E; b->maxR = d->maxR + (d->maxR & 1);
     const size_t E = (size_t)b->E, n = (size_t)b->nant, M = (size_t)b->maxR, ns = n - 1;
     bool ok = hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking) == hipSuccess;
@@ -128,6 +132,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
 extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
 {
     if (!b) { set_error("frirl_hip_batch_episode: NULL batch"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
     int rc = frirl_hip_episode_begin(&b->t, &b->rb, &b->agent, &b->envs, b->s);
     if (rc) return rc;
     hipLaunchKernelGGL(frirl::mask_converged_kernel, dim3((b->E + 255) / 256), dim3(256), 0, b->s, b->d_done, b->d_converged, b->E);
@@ -178,6 +183,7 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
 extern "C" int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *episodes_run)
 {
     if (!b) { set_error("frirl_hip_batch_train: NULL batch"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
     int ep = 0;
     for (ep = 1; ep < max_episodes; ep++) {             // at most max_episodes-1 episodes (frirl_sequential_run.c:51,59)
         int rc = frirl_hip_batch_episode(b);
@@ -195,6 +201,7 @@ extern "C" int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, i
 extern "C" int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out)
 {
     if (!b || !out) { set_error("frirl_hip_batch_stats: NULL"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
     const int E = b->E;
     std::vector<double> rew(E);
     std::vector<int32_t> steps(E), nr(E), cv(E), eps(E);
@@ -221,6 +228,7 @@ extern "C" int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t
 extern "C" int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32_t *R, double *rant, double *rconc)
 {
     if (!b || !R || e < 0 || e >= b->E) { set_error("frirl_hip_batch_get_rulebase: bad arguments"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
     int32_t r = 0;
     BCHK(hipMemcpy(&r, b->d_nrules + e, sizeof(int32_t), hipMemcpyDeviceToHost), "nrules download");
     *R = r;
@@ -238,6 +246,7 @@ extern "C" int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32
 extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strategy, double reward_tolerance, int depth, frirl_hip_reduce_result *result)
 {
     if (!b || !result || e < 0 || e >= b->E) { set_error("frirl_hip_batch_reduce: bad arguments"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t n = b->nant, M = b->maxR;
     frirl_hip_rulebases one = b->rb;                                 // agent e's slab as a rule-base batch of one
     one.E = 1;
@@ -251,6 +260,7 @@ extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strateg
 extern "C" int frirl_hip_batch_save_rulebases(frirl_hip_batch *b, const char *path)
 {
     if (!b || !path) { set_error("frirl_hip_batch_save_rulebases: bad arguments"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t n = b->nant, M = b->maxR, E = b->E;
     std::vector<int32_t> nr(E);
     std::vector<double> rant(E * n * M), rb(E * (n + 1) * M);
@@ -279,6 +289,7 @@ extern "C" int frirl_hip_batch_save_rulebases(frirl_hip_batch *b, const char *pa
 extern "C" int frirl_hip_batch_load_rulebases(frirl_hip_batch *b, const char *path, int32_t *records_read)
 {
     if (!b || !path) { set_error("frirl_hip_batch_load_rulebases: bad arguments"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t n = b->nant, M = b->maxR, E = b->E;
     FILE *fp = fopen(path, "rb");
     if (!fp) { set_error("frirl_hip_batch_load_rulebases: cannot open %s", path); return FRIRL_HIP_EINVAL; }

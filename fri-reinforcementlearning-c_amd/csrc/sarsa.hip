@@ -618,19 +618,27 @@ static void launch_episode_v(const frirl_hip_tables *t, const frirl_hip_rulebase
     const bool idx = frirl::use_uidx(t, b) && (BLOCK == 256 || sizeof(double) * t->nant * (size_t)t->U <= 4096);
     const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
     const bool pn = ag->p <= 0 || ag->p == N;                     // the Shepard power is the default nant: straight-line power (PowC<N>)
-    // spread candidates tracked in the fused sweep: only where the second sweep would be a second pass over HBM (large slabs)
+    // Spread candidates tracked in the fused sweep (sweeps.h: SpreadCand): where the second sweep would be a second pass over HBM
+    // (large slabs) AND the sweep has registers to spare -- measured (tools/step_ab.py): acrobot 65 536 rules x 8 192 envs
+    // 2.47 -> 2.26 ms per step; the 3-antecedent kernels (80-VGPR budget) and the 21-action kernel (already at 128) spill in the hot
+    // loop with it (0.23 -> 0.57 ms, 3.0 -> 5.8 ms) and their second sweep is cheap beside A + 1 Shepard sums per rule, so they keep it.
+    constexpr bool CAN_TRACK = (N >= 4 && AMAX <= 4);
     const int st_opt = frirl_host::opts().step_track;
-    const bool track = st_opt == 1 || (st_opt < 0 && b->maxR > 16384 + 512);
+    const bool track = CAN_TRACK && (st_opt == 1 || (st_opt < 0 && b->maxR > 16384 + 512));
 #define EP_GO(KERNEL, DYN, ...)                                                                                                                  \
     hipLaunchKernelGGL((frirl::KERNEL<N, AMAX, BLOCK, __VA_ARGS__>), dim3(b->E), dim3(BLOCK), DYN, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
                        b->maxR, *ag, *ev)
-    if (BEGIN) {
+    if constexpr (BEGIN) {
         if (idx) { if (pn) EP_GO(episode_begin_kernel, tab, true, true); else EP_GO(episode_begin_kernel, tab, true, false); }
         else { if (pn) EP_GO(episode_begin_kernel, 0, false, true); else EP_GO(episode_begin_kernel, 0, false, false); }
-    } else if (track) {
-        if (idx) { if (pn) EP_GO(episode_step_kernel, tab, true, true, true); else EP_GO(episode_step_kernel, tab, true, false, true); }
-        else { if (pn) EP_GO(episode_step_kernel, 0, false, true, true); else EP_GO(episode_step_kernel, 0, false, false, true); }
     } else {
+        if constexpr (CAN_TRACK) {
+            if (track) {
+                if (idx) { if (pn) EP_GO(episode_step_kernel, tab, true, true, true); else EP_GO(episode_step_kernel, tab, true, false, true); }
+                else { if (pn) EP_GO(episode_step_kernel, 0, false, true, true); else EP_GO(episode_step_kernel, 0, false, false, true); }
+                return;
+            }
+        }
         if (idx) { if (pn) EP_GO(episode_step_kernel, tab, true, true, false); else EP_GO(episode_step_kernel, tab, true, false, false); }
         else { if (pn) EP_GO(episode_step_kernel, 0, false, true, false); else EP_GO(episode_step_kernel, 0, false, false, false); }
     }

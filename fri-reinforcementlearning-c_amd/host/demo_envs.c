@@ -253,38 +253,113 @@ int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, i
     return frirl_demo_batch_run_ex(env, agents, max_episodes, reduce_strategy, NULL, NULL, out_txt, verbose);
 }
 
+/* host tables + agent descriptor of a demo for frirl_hip_batch_create / frirl_hip_multi_create; release with demo_desc_free */
+struct demo_desc_mem { double *u, *ve, *grid, *action_ve, *rant0, *rconc0; };
+
+static int demo_desc_build(const char *env, int agents, frirl_hip_batch_desc *d, struct demo_desc_mem *mm, int *nant_out)
+{
+    int ns, U, A, max_steps, nant, k, j, R0;
+    int grid_len[FRIRL_HIP_MAX_NANT];
+    double grid_div[FRIRL_HIP_MAX_NANT], values_def[FRIRL_HIP_MAX_NANT], hp[8];
+    memset(mm, 0, sizeof *mm);
+    if (frirl_demo_describe(env, &ns, &U, &A, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, &max_steps) != 0) return -1;
+    nant = ns + 1;
+    mm->u = malloc(sizeof(double) * nant * U); mm->ve = malloc(sizeof(double) * nant * U);
+    mm->grid = calloc((size_t)FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID, sizeof(double)); mm->action_ve = calloc(FRIRL_HIP_MAX_ACTIONS, sizeof(double));
+    if (!mm->u || !mm->ve || !mm->grid || !mm->action_ve) return -1;
+    if (frirl_demo_describe(env, &ns, &U, &A, mm->u, mm->ve, mm->grid, grid_len, grid_div, values_def, mm->action_ve, hp, &max_steps) != 0) return -1;
+    R0 = 1 << nant;
+    mm->rant0 = malloc(sizeof(double) * R0 * nant); mm->rconc0 = calloc(R0, sizeof(double));
+    if (!mm->rant0 || !mm->rconc0) return -1;
+    for (k = 0; k < nant; k++) {                               /* frirl_init_rb.c:99-126 */
+        double mn = mm->grid[k * FRIRL_HIP_MAX_GRID], mx = mn;
+        const unsigned int divider = (unsigned int)R0 >> (k + 1);
+        for (j = 0; j < grid_len[k]; j++) { const double v = mm->grid[k * FRIRL_HIP_MAX_GRID + j]; if (v > mx) mx = v; if (v < mn) mn = v; }
+        for (j = 0; j < R0; j++) mm->rant0[j * nant + k] = (((j / divider) % 2) == 0) ? mn : mx;
+    }
+    memset(d, 0, sizeof *d);
+    d->nant = nant; d->U = U; d->E = agents; d->maxR = 1024; d->u = mm->u; d->ve = mm->ve; d->R0 = R0; d->rant0 = mm->rant0; d->rconc0 = mm->rconc0;
+    d->agent.alpha = hp[0]; d->agent.gamma = hp[1]; d->agent.qdiff_pos_boundary = hp[2]; d->agent.qdiff_neg_boundary = hp[3];
+    d->agent.weight_significant = hp[4]; d->agent.skip_rules = (int32_t)hp[5]; d->agent.reward_good_above = hp[6]; d->agent.qdiff_final_tolerance = hp[7];
+    d->agent.p = 0; d->agent.A = A; d->agent.max_steps = max_steps; d->agent.no_random = 1;
+    d->agent.env_kind = !strcmp(env, "mountaincar") ? FRIRL_HIP_ENV_MOUNTAINCAR : (!strcmp(env, "cartpole") ? FRIRL_HIP_ENV_CARTPOLE : FRIRL_HIP_ENV_ACROBOT);
+    for (k = 0; k < nant; k++) { d->agent.grid_len[k] = grid_len[k]; d->agent.grid_div[k] = grid_div[k]; d->agent.values_def[k] = values_def[k]; }
+    d->agent.grid_values = mm->grid; d->agent.action_ve = mm->action_ve;
+    *nant_out = nant;
+    return 0;
+}
+
+static void demo_desc_free(struct demo_desc_mem *mm)
+{
+    free(mm->u); free(mm->ve); free(mm->grid); free(mm->action_ve); free(mm->rant0); free(mm->rconc0);
+}
+
+static int dump_rule_base_txt(const char *out_txt, int nant, int R, const double *rant, const double *rconc)
+{
+    int j, k;
+    FILE *fp = fopen(out_txt, "w");
+    if (!fp) return -1;
+    for (j = 0; j < R; j++) {
+        for (k = 0; k < nant; k++) fprintf(fp, "%.18f ", rant[j * nant + k]);
+        fprintf(fp, "%.18f \n", rconc[j]);
+    }
+    fclose(fp);
+    return 0;
+}
+
+/* `agents` agents of a demo sharded over `gpus` visible devices (0 = all): frirl_hip_multi_* -- one batch and one host thread
+ * per device, the per-episode report all-reduced with RCCL.  Prints the job's report; out_txt (or NULL) receives the rule base of
+ * the agent with global id 0.  Returns the number of converged agents, or -1. */
+int frirl_demo_multi_run(const char *env, int agents, int gpus, int max_episodes, const char *out_txt, int verbose)
+{
+    frirl_hip_batch_desc d;
+    struct demo_desc_mem mm;
+    frirl_hip_multi *m;
+    frirl_hip_batch_stats_t st;
+    int nant = 0, episodes = 0, rc, g;
+    int32_t ng = 0, ver = 0;
+    int64_t start[64], count[64];
+    if (demo_desc_build(env, agents, &d, &mm, &nant) != 0) return -1;
+    m = frirl_hip_multi_create(&d, agents, gpus);
+    if (!m) five_dropin_fatal("frirl_demo_multi_run(create)", FRIRL_HIP_ENODEV);
+    rc = frirl_hip_multi_train(m, max_episodes, &episodes);
+    if (rc) five_dropin_fatal("frirl_demo_multi_run(train)", rc);
+    rc = frirl_hip_multi_stats(m, &st);
+    if (rc) five_dropin_fatal("frirl_demo_multi_run(stats)", rc);
+    frirl_hip_multi_info(m, &ng, &ver, NULL, NULL);
+    if (ng <= 64) frirl_hip_multi_info(m, &ng, &ver, start, count);
+    if (verbose) {
+        printf("multi %s: gpus %d (RCCL %d) agents %lld episodes %d converged %lld env-steps %lld mean-rules %.3f mean-reward %.6f (min %.6f max %.6f)\n", env,
+               (int)ng, (int)ver, (long long)st.agents, episodes, (long long)st.converged, (long long)st.total_env_steps, st.rules_sum / st.agents,
+               st.reward_sum / st.agents, st.reward_min, st.reward_max);
+        for (g = 0; g < ng && ng <= 64; g++) printf("multi %s: device %d runs agents [%lld, %lld)\n", env, g, (long long)start[g], (long long)(start[g] + count[g]));
+    }
+    if (st.full_agents > 0)
+        fprintf(stderr, "Warning: %lld of %lld rule bases are at their capacity of %d rules: further rule insertions were refused\n",
+                (long long)st.full_agents, (long long)st.agents, (int)d.maxR);
+    if (out_txt) {
+        int32_t R = 0;
+        double *rant = malloc(sizeof(double) * 1024 * nant), *rconc = malloc(sizeof(double) * 1024);
+        if (!rant || !rconc || frirl_hip_multi_get_rulebase(m, 0, &R, rant, rconc) != 0 || dump_rule_base_txt(out_txt, nant, R, rant, rconc) != 0) {
+            fprintf(stderr, "frirl_demo_multi_run: cannot dump rule base\n");
+            return -1;
+        }
+        free(rant); free(rconc);
+    }
+    frirl_hip_multi_destroy(m);
+    demo_desc_free(&mm);
+    return (int)st.converged;
+}
+
 int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int reduce_strategy, const char *load_bin, const char *save_bin,
                             const char *out_txt, int verbose)
 {
-    int ns, U, A, max_steps, nant, k, j, R0, episodes = 0, rc;
-    double *u, *ve, *grid, *action_ve, *rant0, *rconc0;
-    int grid_len[FRIRL_HIP_MAX_NANT];
-    double grid_div[FRIRL_HIP_MAX_NANT], values_def[FRIRL_HIP_MAX_NANT], hp[8];
+    int nant = 0, episodes = 0, rc;
     frirl_hip_batch_desc d;
+    struct demo_desc_mem mm;
     frirl_hip_batch *b;
     frirl_hip_batch_stats_t st;
-    if (frirl_demo_describe(env, &ns, &U, &A, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, &max_steps) != 0) return -1;
-    nant = ns + 1;
-    u = malloc(sizeof(double) * nant * U); ve = malloc(sizeof(double) * nant * U);
-    grid = calloc((size_t)FRIRL_HIP_MAX_NANT * FRIRL_HIP_MAX_GRID, sizeof(double)); action_ve = calloc(FRIRL_HIP_MAX_ACTIONS, sizeof(double));
-    if (!u || !ve || !grid || !action_ve) return -1;
-    if (frirl_demo_describe(env, &ns, &U, &A, u, ve, grid, grid_len, grid_div, values_def, action_ve, hp, &max_steps) != 0) return -1;
-    R0 = 1 << nant;
-    rant0 = malloc(sizeof(double) * R0 * nant); rconc0 = calloc(R0, sizeof(double));
-    for (k = 0; k < nant; k++) {                               /* frirl_init_rb.c:99-126 */
-        double mn = grid[k * FRIRL_HIP_MAX_GRID], mx = mn;
-        const unsigned int divider = (unsigned int)R0 >> (k + 1);
-        for (j = 0; j < grid_len[k]; j++) { const double v = grid[k * FRIRL_HIP_MAX_GRID + j]; if (v > mx) mx = v; if (v < mn) mn = v; }
-        for (j = 0; j < R0; j++) rant0[j * nant + k] = (((j / divider) % 2) == 0) ? mn : mx;
-    }
-    memset(&d, 0, sizeof d);
-    d.nant = nant; d.U = U; d.E = agents; d.maxR = 1024; d.u = u; d.ve = ve; d.R0 = R0; d.rant0 = rant0; d.rconc0 = rconc0;
-    d.agent.alpha = hp[0]; d.agent.gamma = hp[1]; d.agent.qdiff_pos_boundary = hp[2]; d.agent.qdiff_neg_boundary = hp[3];
-    d.agent.weight_significant = hp[4]; d.agent.skip_rules = (int32_t)hp[5]; d.agent.reward_good_above = hp[6]; d.agent.qdiff_final_tolerance = hp[7];
-    d.agent.p = 0; d.agent.A = A; d.agent.max_steps = max_steps; d.agent.no_random = 1;
-    d.agent.env_kind = !strcmp(env, "mountaincar") ? FRIRL_HIP_ENV_MOUNTAINCAR : (!strcmp(env, "cartpole") ? FRIRL_HIP_ENV_CARTPOLE : FRIRL_HIP_ENV_ACROBOT);
-    for (k = 0; k < nant; k++) { d.agent.grid_len[k] = grid_len[k]; d.agent.grid_div[k] = grid_div[k]; d.agent.values_def[k] = values_def[k]; }
-    d.agent.grid_values = grid; d.agent.action_ve = action_ve;
+    if (demo_desc_build(env, agents, &d, &mm, &nant) != 0) return -1;
     d.agent.evaluate = load_bin ? 1 : 0;          /* loaded rule bases are replayed greedily, not trained (frirl_test_run.c:66-70) */
     b = frirl_hip_batch_create(&d);
     if (!b) five_dropin_fatal("frirl_demo_batch_run(create)", FRIRL_HIP_ENODEV);
@@ -323,15 +398,13 @@ int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int r
     if (out_txt) {
         int32_t R = 0;
         double *rant = malloc(sizeof(double) * 1024 * nant), *rconc = malloc(sizeof(double) * 1024);
-        FILE *fp = fopen(out_txt, "w");
-        if (!rant || !rconc || !fp || frirl_hip_batch_get_rulebase(b, 0, &R, rant, rconc) != 0) { fprintf(stderr, "frirl_demo_batch_run: cannot dump rule base\n"); return -1; }
-        for (j = 0; j < R; j++) {
-            for (k = 0; k < nant; k++) fprintf(fp, "%.18f ", rant[j * nant + k]);
-            fprintf(fp, "%.18f \n", rconc[j]);
+        if (!rant || !rconc || frirl_hip_batch_get_rulebase(b, 0, &R, rant, rconc) != 0 || dump_rule_base_txt(out_txt, nant, R, rant, rconc) != 0) {
+            fprintf(stderr, "frirl_demo_batch_run: cannot dump rule base\n");
+            return -1;
         }
-        fclose(fp); free(rant); free(rconc);
+        free(rant); free(rconc);
     }
     frirl_hip_batch_destroy(b);
-    free(u); free(ve); free(grid); free(action_ve); free(rant0); free(rconc0);
+    demo_desc_free(&mm);
     return (int)st.converged;
 }

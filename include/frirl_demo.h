@@ -28,4 +28,8 @@ int frirl_demo_batch_run_reduce(const char *env, int agents, int max_episodes, i
 int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int reduce_strategy, const char *load_bin, const char *save_bin,
                             const char *out_txt, int verbose);   /* save_bin != NULL: all agents' rule bases (before the reduction) go there */
 
+/* `agents` agents over `gpus` devices of this node (0 = every visible device) through frirl_hip_multi_* (one batch + host thread per
+ * device, per-episode report all-reduced with RCCL); out_txt = rule base of global agent 0.  Returns the converged agents or -1. */
+int frirl_demo_multi_run(const char *env, int agents, int gpus, int max_episodes, const char *out_txt, int verbose);
+
 #endif

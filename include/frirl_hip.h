@@ -401,6 +401,8 @@ typedef struct frirl_hip_batch_desc {
     const double *rant0;              /* HOST [R0][nant] raw antecedents (AoS, like FIVERB.rant)               */
     const double *rconc0;             /* HOST [R0]                                                             */
     const double *start_states;       /* HOST [E][nant-1] per-agent episode start state, or NULL = agent.values_def */
+    int32_t device_select;            /* 0 = the calling thread's current device; 1 = the device with ordinal `device`          */
+    int32_t device;                   /* device ordinal when device_select == 1; every frirl_hip_batch_* call switches to it   */
 } frirl_hip_batch_desc;
 
 /* statistics of frirl_hip_batch_stats(): what the reference prints per episode (frirl_sequential_run.c:77-80), summed */
@@ -434,6 +436,31 @@ int frirl_hip_batch_load_rulebases(frirl_hip_batch *b, const char *path, int32_t
 /* frirl_sequential_run's reduction phase (frirl_sequential_run.c:170-350) for agent e's rule base, in place, through
  * frirl_hip_reduce_shared (speculative batched try-remove); the other agents are untouched */
 int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strategy, double reward_tolerance, int depth, frirl_hip_reduce_result *result);
+
+/* =================================================================================================
+ * Many agents over several GPUs of one node, from plain C (the reference's frirl_omp_run / frirl_mpi_run shape,
+ * src/frirl/frirl_agent.c:294-467, without the rule-base merge): `total_agents` agents are sharded over `ngpus` visible
+ * devices by GLOBAL environment id (frirl_hip_shard: balanced contiguous partition; RNG streams and start states are keyed by
+ * the global id, so trajectories do not depend on the sharding), one frirl_hip_batch and one host thread per device, no
+ * data-path collective.  The only exchange is the per-episode report (sums of reward / steps / rules / converged, reward
+ * min / max; frirl_sequential_run.c:74-80): RCCL all-reduce over xGMI, one communicator per device in this single process
+ * (ncclCommInitAll).  RCCL is loaded at first use (dlopen "librccl.so.1"); the library does not link against it.
+ * ================================================================================================= */
+typedef struct frirl_hip_multi frirl_hip_multi;
+/* rank's slice [*start, *start + *count) of `total` environment ids split over `world` ranks (counts differ by at most 1) */
+int frirl_hip_shard(int64_t total, int32_t world, int32_t rank, int64_t *start, int64_t *count);
+/* d: as for frirl_hip_batch_create (d->E, d->device* ignored; d->start_states, if given, HOST [total_agents][nant-1]);
+ * ngpus <= 0: every visible device */
+frirl_hip_multi *frirl_hip_multi_create(const frirl_hip_batch_desc *d, int64_t total_agents, int32_t ngpus);
+void frirl_hip_multi_destroy(frirl_hip_multi *m);
+/* frirl_sequential_run's construct loop on every device at once; stops when the ALL-REDUCED report says every agent converged */
+int frirl_hip_multi_train(frirl_hip_multi *m, int32_t max_episodes, int32_t *episodes_run);
+/* the report of the whole job (all-reduced over the devices) */
+int frirl_hip_multi_stats(frirl_hip_multi *m, frirl_hip_batch_stats_t *out);
+/* *ngpus devices in use, RCCL version code, per-device shard [start, count) (arrays of >= *ngpus entries, or NULL) */
+int frirl_hip_multi_info(const frirl_hip_multi *m, int32_t *ngpus, int32_t *rccl_version, int64_t *shard_start, int64_t *shard_count);
+/* rule base of the agent with GLOBAL id `agent` (as frirl_hip_batch_get_rulebase) */
+int frirl_hip_multi_get_rulebase(frirl_hip_multi *m, int64_t agent, int32_t *R, double *rant, double *rconc);
 
 #ifdef __cplusplus
 }

@@ -205,7 +205,7 @@ def test_fused_episode_steps_follow_oracle(env, n_episodes):
         assert (envs.fus.cpu().numpy() == int(fr.fus)).all()
 
 
-@pytest.mark.parametrize("env,E,R", [("mountaincar", 300, 3000), ("acrobot", 300, 6000), ("cartpole", 64, 5000), ("acrobot", 40, 1500)])
+@pytest.mark.parametrize("env,E,R", [("acrobot", 300, 6000), ("acrobot", 40, 1500), ("acrobot", 5000, 3000), ("mountaincar", 300, 3000), ("cartpole", 64, 5000)])
 def test_spread_candidates_equal_the_second_sweep(env, E, R, hip_option):
     """update_rules' masked write-back (frirl_update_sarsa.c:89-120) from the candidates tracked during the Q(s,a) sweep must
     give the bits of the reference-shaped second sweep (agent.debug_flags bit 0 forces it) -- every step kernel form
@@ -213,7 +213,7 @@ def test_spread_candidates_equal_the_second_sweep(env, E, R, hip_option):
     rules (near-duplicate rules planted in one lane's slots: the workgroup must fall back to the sweep)."""
     import torch
     dev0 = torch.device("cuda", 0)
-    hip_option("step_track", 1)          # by default only rule bases > 16 K rules use the candidates
+    hip_option("step_track", 1)          # by default only rule bases > 16 K rules use the candidates (5-antecedent, <= 4-action kernels)
     outs = []
     for flags in (0, 1):
         prob, agent, envs = frirl_amd.demo_batch(env, E, R, R + 256, dev0, seed=13)

@@ -1,0 +1,56 @@
+"""Several GPUs from plain C (frirl_hip_multi_*: one batch + host thread per device, environments sharded by global id, the
+per-episode report all-reduced with RCCL).  CPU: the shard arithmetic (== the Python sharding used by bench.py / dist.py).
+GPU (one device on the test box): `frirl_demo --agents N --gpus 1` goes through ncclCommInitAll / ncclAllReduce for real and
+must reproduce the single-batch result."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import frirl_amd
+
+
+def test_shard_arithmetic_matches_python_sharding():
+    lib = frirl_amd.lib()
+    D = frirl_amd.dist()
+    for total in (0, 1, 7, 8, 65536, 65537, 1000003):
+        for world in (1, 2, 3, 8):
+            seen = 0
+            for rank in range(world):
+                s, c = C.c_int64(), C.c_int64()
+                assert lib.frirl_hip_shard(total, world, rank, C.byref(s), C.byref(c)) == 0
+                assert (s.value, c.value) == D.shard(total, world, rank)
+                assert s.value == seen
+                seen += c.value
+            assert seen == total
+    s, c = C.c_int64(), C.c_int64()
+    assert lib.frirl_hip_shard(10, 2, 2, C.byref(s), C.byref(c)) == -2          # rank outside the world: EINVAL
+
+
+def test_multi_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert frirl_amd.lib().frirl_hip_multi_create(None, 8, 1) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,rules,steps", [("mountaincar", 110, 15548), ("acrobot", 367, 21207)])
+def test_c_level_multi_gpu_runner_on_one_device(env, rules, steps, tmp_path):
+    from oracle import binding as ob
+    frirl_amd.build()
+    demo = os.path.join(frirl_amd.PKG_DIR, "lib", "frirl_demo")
+    r = subprocess.run([demo, "--env", env, "--agents", "70", "--gpus", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "gpus 1 (RCCL" in r.stdout and "converged 70" in r.stdout and "device 0 runs agents [0, 70)" in r.stdout, r.stdout
+    assert f"env-steps {70 * steps}" in r.stdout, r.stdout
+    mine = np.loadtxt(tmp_path / f"{env}.multi.frirlrb.txt", dtype=np.float64, ndmin=2)
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1
+    f = fr.five
+    assert mine.shape == (rules, f.nant + 1)
+    assert (mine[:, :-1] == np.array(f.rant[:rules])).all()
+    rel = np.abs(mine[:, -1] - f.rconc[:rules]) / np.maximum(np.abs(f.rconc[:rules]), 1e-9)
+    assert rel.max() <= 1e-6
