@@ -615,7 +615,7 @@ static void launch_episode_v(const frirl_hip_tables *t, const frirl_hip_rulebase
 {
     // compressed index mirror: large rule bases only (use_uidx); with one wave per environment only while the per-workgroup
     // LDS copy of the VE tables is small (<= 4 KiB: it does not limit the waves per CU)
-    const bool idx = frirl::use_uidx(t, b) && (BLOCK == 256 || sizeof(double) * t->nant * (size_t)t->U <= 4096);
+    const bool idx = frirl::use_uidx(t, b) && (BLOCK >= 256 || sizeof(double) * t->nant * (size_t)t->U <= 4096);
     const size_t tab = idx ? sizeof(double) * t->nant * (size_t)t->U : 0;
     const bool pn = ag->p <= 0 || ag->p == N;                     // the Shepard power is the default nant: straight-line power (PowC<N>)
     // Spread candidates tracked in the fused sweep (sweeps.h: SpreadCand): where the second sweep would be a second pass over HBM
@@ -656,7 +656,10 @@ static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases 
     // one wave per environment: small rule bases, or mid-size ones when the environments alone fill the chip (>= 4 waves
     // per SIMD): measured at 8192 rules x 8192 envs 0.320 -> 0.295 ms per step; at 65 536 rules the 256-thread form wins
     bool small = b->maxR <= 2048 || (b->maxR <= 16384 && b->E >= 4096);
-    if (frirl_host::opts().step_wave >= 0) small = frirl_host::opts().step_wave == 1;
+    // (1024 threads per environment -- fewer environments in flight, fewer concurrent DRAM streams -- measured slower at 65 536 rules:
+    //  2.27 -> 2.79 ms per step, tools/step_ab.py)
+    const int sw = frirl_host::opts().step_wave;
+    if (sw >= 0) small = sw == 1;
     if (ag->A <= 4) { if (small) launch_episode_v<N, 4, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 4, 256, BEGIN>(t, b, ag, ev, s); }
     else if (ag->A <= 8) { if (small) launch_episode_v<N, 8, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 8, 256, BEGIN>(t, b, ag, ev, s); }
     else launch_episode_v<N, 32, 256, BEGIN>(t, b, ag, ev, s);            // > 8 actions: action-parallel waves (sweep_gba_wide)
