@@ -71,6 +71,8 @@ def lib():
         "orc_five_best_action": (C.c_uint, [F, c_double_p, c_double_p, i, c_double_p]),
         "orc_five_update_sarsa": (None, [F, C.POINTER(OrcAgent), c_double_p, c_double_p, d, c_double_p]),
         "orc_frirl_agent": (None, [vp, C.POINTER(OrcAgent)]),
+        "orc_merge_rb": (None, [F, C.POINTER(OrcAgent), c_double_p, c_double_p, i]),
+        "orc_gen_def_states": (i, [F, i, i, i, c_double_p]),
         "orc_frirl_new": (vp, [i, i, i]),
         "orc_frirl_delete": (None, [vp]),
         "orc_frirl_frb": (F, [vp]),
@@ -265,6 +267,17 @@ class Five:
         f = C.c_double(fus)
         lib().orc_five_update_sarsa(self.h, C.byref(agent.c), C.byref(f), dp(a), float(reward), dp(b))
         return f.value
+
+    def merge_rb(self, agent, rant, rconc):
+        """merge_rb (reference frirl_agent.c:58-117): this rule base takes over the sender's rules rant [S][nant], rconc [S]."""
+        ra = np.ascontiguousarray(rant, dtype=np.float64)
+        rc = np.ascontiguousarray(rconc, dtype=np.float64)
+        lib().orc_merge_rb(self.h, C.byref(agent.c), dp(ra), dp(rc), len(rc))
+
+    def gen_def_states(self, agent_id, worldsize, nstates):
+        """gen_def_states (frirl_agent.c:121-139) with THIS rule base as the master's: start state of agent `agent_id`, or None."""
+        out = np.zeros(nstates)
+        return out if lib().orc_gen_def_states(self.h, agent_id, worldsize, nstates, dp(out)) else None
 
     def device_layout(self, maxR=None):
         """rb[nant+1][maxR] float64: antecedent VE values per dimension, then consequents."""

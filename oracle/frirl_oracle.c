@@ -774,6 +774,48 @@ void orc_five_update_sarsa(orc_five *f, const orc_agent *ag, double *fus, const 
     orc_update_rules(f, ag, fus, q_ant, qnow, qdiff);
 }
 
+/* src/frirl/frirl_agent.c:58-117 (merge_rb, the BUILD_OPENMP / BUILD_MPI body; CHECK_STATES = 1): the receiver takes over the
+ * sender's rules one after the other.  Per sender rule: receiver's Shepard weights (left untouched on an exact hit, so a later
+ * hit re-uses the weights of the last interpolated rule -- :72 passes the receiver's own weights array) and conclusion at the
+ * sender's antecedents; qdiff = sender Q - receiver Q (:82).  Outside the qdiff boundaries the antecedents are snapped to the
+ * receiver's rule grid (:96-99): a new place gets a new rule with the mean of the two conclusions (:101), an existing one moves
+ * 10 % towards the sender (:105); inside the boundaries every rule with weight > delta is OVERWRITTEN with q * weight,
+ * q = 0.9 receiver + 0.1 sender (:45-53 -- the agent file's own update_rules, not frirl_update_sarsa.c's). */
+void orc_merge_rb(orc_five *rcvr, const orc_agent *ag, const double *newrant, const double *newrconc, int numofrules)
+{
+    const int n = rcvr->nant;
+    for (int r = 0; r < numofrules; r++) {
+        const double *sndr_rant = newrant + (size_t)r * n;
+        const double sndr_rconc = newrconc[r];
+        unsigned rcvr_rule_i = orc_vag_concl_weight(rcvr, sndr_rant, rcvr->weights);
+        double rcvr_rconc;
+        orc_vag_concl(rcvr, sndr_rant, &rcvr_rconc);
+        const double qdiff = -rcvr_rconc + sndr_rconc;
+        if (qdiff > ag->qdiff_pos_boundary || qdiff < ag->qdiff_neg_boundary) {
+            double rant[ORC_MAX_NANT], rconc = rcvr_rconc;
+            for (int i = 0; i < n; i++) rant[i] = orc_check_possible_states(sndr_rant[i], ag->grid[i], ag->grid_len[i]);
+            rcvr_rule_i = orc_vag_concl(rcvr, rant, &rconc);
+            if (rcvr_rule_i == ~0u) { orc_add_rule(rcvr, rant, 0.5 * rconc + 0.5 * sndr_rconc); continue; }
+            rcvr->rconc[rcvr_rule_i] = 0.9 * rconc + 0.1 * sndr_rconc;
+            continue;
+        }
+        const double q = 0.9 * rcvr_rconc + 0.1 * sndr_rconc;
+        for (int w = 0; w < rcvr->R; w++)
+            if (rcvr->weights[w] > ag->weight_significant) rcvr->rconc[w] = q * rcvr->weights[w];
+    }
+}
+
+/* src/frirl/frirl_agent.c:121-139 (gen_def_states): agent `id` of `worldsize` starts its episodes from the state antecedents of
+ * the master's rule (id-1) * gap, gap = numofrules / (worldsize - 2) (integer division as written: worldsize 2 divides by zero
+ * in the reference; callers here use worldsize >= 3).  Agent 0 keeps its start state (returns 0). */
+int orc_gen_def_states(const orc_five *master, int id, int worldsize, int nstates, double *values_def)
+{
+    if (id == 0 || worldsize < 3) return 0;
+    const int gap = master->R / (worldsize - 2);
+    for (int i = 0; i < nstates; i++) values_def[i] = master->rant[(size_t)(id - 1) * gap * master->nant + i];
+    return 1;
+}
+
 void orc_frirl_agent(const orc_frirl *fr, orc_agent *ag)
 {
     memset(ag, 0, sizeof(*ag));

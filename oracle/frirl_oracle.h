@@ -121,6 +121,8 @@ typedef struct orc_agent {
 unsigned orc_five_best_action(orc_five *f, const double *states, const double *action_ve, int A, double *actconc);
 void orc_five_update_sarsa(orc_five *f, const orc_agent *ag, double *fus, const double *q_ant, double reward, const double *cur_q_ant);
 void orc_frirl_agent(const orc_frirl *fr, orc_agent *ag);
+void orc_merge_rb(orc_five *rcvr, const orc_agent *ag, const double *newrant, const double *newrconc, int numofrules);   /* frirl_agent.c:58-117 */
+int orc_gen_def_states(const orc_five *master, int id, int worldsize, int nstates, double *values_def);               /* frirl_agent.c:121-139 */
 
 void orc_frirl_config(orc_frirl *fr, int env);     /* examples/<env>/<env>.c main(): hyper-parameters as data */
 int  orc_frirl_init(orc_frirl *fr);                /* frirl_init.c:29-341, frirl_init_ve.c:25-121, frirl_init_rb.c:86-147 */

@@ -14,6 +14,9 @@ reference's exported C API and each example's own main().  What is committed is 
   tests/golden/vec_<env>.jsonl        function-level vectors (tables, index snap, rule distance,
                                       vag_concl, weights, best action, SARSA updates, env steps)
                                       on the rule base reached after a few episodes
+  tests/golden/merge_<env>.jsonl      multi-agent rule-base merge (frirl_agent.c merge_rb / gen_def_states / omp_init, compiled with
+                                      BUILD_OPENMP by oracle/_ref/ref_merge_harness): master and agent rule bases before and
+                                      after merging in both directions
   tests/golden/synth_*.jsonl          hashes for large synthetic rule bases (inputs are re-created
                                       in the tests by oracle orc_synth_*; nant <= 8 only, the
                                       reference's cap is FIVE_MAX_NUM_OF_UNIVERSES = 8)
@@ -27,6 +30,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 ENVS = ["mountaincar", "cartpole", "acrobot"]
 VEC_EPISODES = {"mountaincar": 6, "cartpole": 9, "acrobot": 5}
+MERGE_EPISODES = {"mountaincar": (8, 3), "cartpole": (10, 4), "acrobot": (6, 3)}
 SYNTH = [  # nant, U, R, A, seed, nq
     (3, 41, 33, 3, 11, 64),
     (5, 41, 367, 3, 12, 64),
@@ -52,18 +56,24 @@ def main():
                         os.path.join(GOLD, "orig", f"frirl_example_{e}.frirlrb.txt"))
     tmp = "/tmp/frirl_golden"
     os.makedirs(tmp, exist_ok=True)
-    for e in ENVS:
+    for e in ([] if "--merge-only" in sys.argv else ENVS):
         with open(os.path.join(tmp, f"{e}.stdout"), "w") as so:
             run(HARNESS, "demo", e, tmp, stdout=so)
         shutil.copyfile(os.path.join(tmp, f"{e}.frirlrb.txt"), os.path.join(GOLD, f"ref_{e}.frirlrb.txt"))
         shutil.copyfile(os.path.join(tmp, f"{e}.trace.jsonl"), os.path.join(GOLD, f"ref_{e}.trace.jsonl"))
         with open(os.path.join(tmp, f"{e}.vstdout"), "w") as so:
             run(HARNESS, "vectors", e, os.path.join(GOLD, f"vec_{e}.jsonl"), str(VEC_EPISODES[e]), stdout=so)
-    for e in ENVS:
+    for e in ([] if "--merge-only" in sys.argv else ENVS):
         for strategy in (1, 2):
             with open(os.path.join(tmp, f"{e}.rstdout"), "w") as so:
                 run(HARNESS, "reduce", e, tmp, str(strategy), stdout=so)
             shutil.copyfile(os.path.join(tmp, f"{e}.reduced{strategy}.frirlrb.txt"), os.path.join(GOLD, f"ref_{e}.reduced{strategy}.frirlrb.txt"))
+    for e in ENVS:      # (master episodes, agent episodes): early rule bases, so that the merge inserts, blends and spreads
+        m_eps, a_eps = MERGE_EPISODES[e]
+        with open(os.path.join(tmp, f"{e}.mstdout"), "w") as so:
+            run(os.path.join(HERE, "_ref", "ref_merge_harness"), e, os.path.join(GOLD, f"merge_{e}.jsonl"), str(m_eps), str(a_eps), stdout=so)
+    if "--merge-only" in sys.argv:
+        return
     for (nant, U, R, A, seed, nq) in SYNTH:
         run(HARNESS, "synth", str(nant), str(U), str(R), str(A), str(seed), str(nq),
             os.path.join(GOLD, f"synth_n{nant}_u{U}_r{R}.jsonl"))

@@ -291,3 +291,49 @@ def test_reduction_matches_reference(env, strategy, golden_dir, tmp_path):
     fr.save_text(p)
     with open(p) as a, open(os.path.join(golden_dir, f"ref_{env}.reduced{strategy}.frirlrb.txt")) as b:
         assert a.read() == b.read()
+
+
+MERGE_EPISODES = {"mountaincar": (8, 3), "cartpole": (10, 4), "acrobot": (6, 3)}
+
+
+def merge_records(env, golden_dir):
+    recs = {r["k"]: r for r in load_jsonl(os.path.join(golden_dir, f"merge_{env}.jsonl"))}
+    assert (recs["hdr"]["master_episodes"], recs["hdr"]["agent_episodes"]) == MERGE_EPISODES[env]
+    return recs
+
+
+def same_rule_base(five, rec, nant):
+    R = rec["R"]
+    assert five.R == R, (five.R, R)
+    assert (bits(five.rant[:R]) == bits(fha(rec["rant"]).reshape(R, nant))).all(), "antecedents / rule order"
+    assert (bits(five.rconc[:R]) == bits(fha(rec["rconc"]))).all(), "consequents"
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_merge_rb_matches_reference(env, golden_dir):
+    """merge_rb / gen_def_states / omp_init of the GENUINE reference (frirl_agent.c compiled with BUILD_OPENMP by
+    oracle/Makefile, driven by oracle/ref_merge_harness.c): a master after M episodes, agent 1 of a world of 3 (fresh rule
+    base, start state moved to the master's first rule) after K episodes, then agent <- master and master <- agent.  The
+    oracle's restatement reproduces every rule base bit for bit."""
+    recs = merge_records(env, golden_dir)
+    m_eps, a_eps = MERGE_EPISODES[env]
+    master = ob.Frirl(env)
+    for _ in range(m_eps):
+        master.episode()
+    nant = master.five.nant
+    same_rule_base(master.five, recs["master_before"], nant)
+    start = master.five.gen_def_states(1, 3, master.nstates)
+    assert (bits(start) == bits(fha(recs["agent_start"]["values_def"]))).all()
+    assert master.five.gen_def_states(0, 3, master.nstates) is None
+    agent = ob.Frirl(env)
+    agent.set_start_state(start)
+    for _ in range(a_eps):
+        agent.episode()
+    same_rule_base(agent.five, recs["agent_before"], nant)
+    Rm = master.five.R
+    agent.five.merge_rb(agent.agent(), np.array(master.five.rant[:Rm]), np.array(master.five.rconc[:Rm]))
+    same_rule_base(agent.five, recs["agent_after"], nant)
+    Ra = agent.five.R
+    master.five.merge_rb(master.agent(), np.array(agent.five.rant[:Ra]), np.array(agent.five.rconc[:Ra]))
+    same_rule_base(master.five, recs["master_after"], nant)
+    assert recs["agent_after"]["R"] > recs["agent_before"]["R"], "the merge inserted rules"
