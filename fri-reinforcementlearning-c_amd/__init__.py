@@ -59,6 +59,12 @@ class RolloutDesc(C.Structure):
                 ("reward", C.c_void_p), ("success", C.c_void_p), ("final_states", C.c_void_p)]
 
 
+class SenderDesc(C.Structure):
+    """struct frirl_hip_sender (include/frirl_hip.h)."""
+    _fields_ = [("rant", C.c_void_p), ("rule_stride", C.c_int64), ("dim_stride", C.c_int64), ("rconc", C.c_void_p), ("S", C.c_int32),
+                ("reserved", C.c_int32), ("S_dev", C.c_void_p)]
+
+
 class ReduceResult(C.Structure):
     """struct frirl_hip_reduce_result (include/frirl_hip.h)."""
     _fields_ = [("rules_before", C.c_int32), ("rules_after", C.c_int32), ("rounds", C.c_int32), ("rollouts", C.c_int32),
@@ -112,6 +118,7 @@ SIGNATURES = {
     "frirl_hip_convergence_init": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(ConvergenceDesc), C.c_void_p]),
     "frirl_hip_convergence_update": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
                                                C.c_void_p]),
+    "frirl_hip_convergence_refresh": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.POINTER(ConvergenceDesc), C.c_void_p]),
     "five_hip_bestact": (C.c_int, [C.POINTER(RuleBases), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     # library-owned batch with host descriptors (C-level many-agent runner)
     "frirl_hip_batch_create": (C.c_void_p, [C.c_void_p]),
@@ -123,6 +130,11 @@ SIGNATURES = {
     "frirl_hip_batch_save_rulebases": (C.c_int, [C.c_void_p, C.c_char_p]),
     "frirl_hip_batch_load_rulebases": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "frirl_hip_batch_reduce": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, C.c_double, C.c_int, C.POINTER(ReduceResult)]),
+    "frirl_hip_batch_merge_round": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "frirl_hip_batch_train_merged": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "frirl_hip_merge_rb": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_void_p, C.POINTER(SenderDesc), C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frirl_hip_gen_def_states": (C.c_int, [_DP, C.c_int32, C.c_int32, C.c_int32, _DP, _DP]),
     # several GPUs from plain C (one batch + host thread per device, RCCL all-reduce of the report)
     "frirl_hip_shard": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "frirl_hip_multi_create": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int32]),
@@ -324,6 +336,18 @@ class Problem:
                                             strategy, reward_tolerance, depth, kept.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(res), _stream(stream)),
               "frirl_hip_reduce_shared")
         return kept[: res.rules_after], res
+
+    def merge_rb(self, agent, sndr_rant, sndr_rconc, weights, rant_store=None, active=None, stream=None):
+        """frirl_hip_merge_rb: every (active) rule base of this batch takes over the sender rules sndr_rant [S][nant] (AoS),
+        sndr_rconc [S]; weights [E][maxR] persists between calls (zeros at first).  Returns full [E] int32."""
+        import torch
+        S = sndr_rconc.numel()
+        assert sndr_rant.shape == (S, self.nant) and sndr_rant.is_contiguous() and weights.shape == (self.E, self.maxR)
+        snd = SenderDesc(sndr_rant.data_ptr(), self.nant, 1, sndr_rconc.data_ptr(), S, 0, None)
+        full = torch.zeros((self.E,), dtype=torch.int32, device=self.rb.device)
+        check(lib().frirl_hip_merge_rb(C.byref(self.tables), C.byref(self.bases), C.byref(agent.desc), _ptr(rant_store), C.byref(snd), _ptr(weights),
+                                       _ptr(active), _ptr(full), _stream(stream)), "frirl_hip_merge_rb")
+        return full
 
     def add_rule(self, rant, rconc, active=None, rant_store=None, stream=None):
         """five_hip_add_rule: appends rant[e] -> rconc[e]; returns added [E] int32."""

@@ -17,6 +17,9 @@ struct frirl_hip_batch {
     hipStream_t s;
     double *d_u, *d_ve, *d_rb, *d_rant, *d_grid, *d_ave, *d_states, *d_q_ant, *d_ep_reward, *d_start, *d_prev_reward, *d_prev_rconc, *d_tmp;
     uint16_t *d_uidx;            // 16-bit universe-index mirror of the antecedents (compressed scans, lane-group index store)
+    double *d_weights;           // [E][maxR] FIVERB.weights of every agent (rule-base merge; allocated on first use)
+    uint8_t *d_active;           // [E] receiver mask of a merge round
+    int32_t *d_full;             // [E] append refused during a merge
     void *d_lanes_ws;            // transposed rule bases of the lane-group kernel (allocated on first use)
     size_t lanes_ws_bytes;
     int32_t *d_nrules, *d_fus, *d_done, *d_ep_steps, *d_status, *d_episode, *d_prev_nrules, *d_prev_steps, *d_converged, *d_episodes;
@@ -70,7 +73,7 @@ extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
     if (b->s) (void)hipStreamSynchronize(b->s);
     void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
                     b->d_prev_rconc, b->d_tmp, b->d_nrules, b->d_fus, b->d_done, b->d_ep_steps, b->d_status, b->d_episode, b->d_prev_nrules,
-                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_uidx, b->d_lanes_ws};
+                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_uidx, b->d_lanes_ws, b->d_weights, b->d_active, b->d_full};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->s) (void)hipStreamDestroy(b->s);
     delete b;
@@ -254,6 +257,78 @@ extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strateg
     one.nrules = b->d_nrules + e;
     if (one.uidx) one.uidx = b->rb.uidx + (size_t)e * n * M;
     return frirl_hip_reduce_shared(&b->t, &one, &b->agent, b->d_rant + (size_t)e * n * M, strategy, reward_tolerance, depth, nullptr, result, b->s);
+}
+
+// ---- multi-agent rule-base merge: one round of the reference's many-agent loop (frirl_agent.c:426-462) -------------------
+// (1) every agent id >= 1 takes over the master's (agent 0's) rules -- all receivers in ONE launch; (2) the master takes over the
+// rules of agent 1, 2, ... one after the other (sequential by definition: each merge changes the master).  Agents whose rule base
+// is complete ("epended": converged[]) do not send, as in the reference (:432,:444).
+extern "C" int frirl_hip_batch_merge_round(frirl_hip_batch *b, int32_t *full_agents)
+{
+    if (!b) { set_error("frirl_hip_batch_merge_round: NULL batch"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    const size_t n = b->nant, M = b->maxR, E = b->E;
+    if (full_agents) *full_agents = 0;
+    if (E < 2) return FRIRL_HIP_OK;
+    if (!b->d_weights) {
+        if (!dalloc(&b->d_weights, E * M) || !dalloc(&b->d_active, E) || !dalloc(&b->d_full, E)) { set_error("frirl_hip_batch_merge_round: allocation failed"); return FRIRL_HIP_ELAUNCH; }
+    }
+    b->h_i.resize(E);
+    BCHK(hipMemcpyAsync(b->h_i.data(), b->d_converged, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "converged download");
+    BCHK(hipStreamSynchronize(b->s), "merge sync");
+    std::vector<int32_t> conv(b->h_i.begin(), b->h_i.begin() + E);
+    int rc;
+    frirl_hip_sender snd;
+    memset(&snd, 0, sizeof snd);
+    snd.rule_stride = 1; snd.dim_stride = (int64_t)M;
+    if (!conv[0]) {                                                   // (1) master -> every other agent
+        std::vector<uint8_t> act(E, 1);
+        act[0] = 0;
+        BCHK(hipMemcpyAsync(b->d_active, act.data(), E, hipMemcpyHostToDevice, b->s), "active upload");
+        snd.rant = b->d_rant; snd.rconc = b->d_rb + n * M; snd.S_dev = b->d_nrules;
+        if ((rc = frirl_hip_merge_rb(&b->t, &b->rb, &b->agent, b->d_rant, &snd, b->d_weights, b->d_active, b->d_full, b->s))) return rc;
+        BCHK(hipStreamSynchronize(b->s), "merge sync");              // `act` must outlive the upload
+    }
+    frirl_hip_rulebases master = b->rb;                                // (2) agent id -> master, id ascending
+    master.E = 1;
+    for (size_t id = 1; id < E; id++) {
+        if (conv[id]) continue;
+        snd.rant = b->d_rant + id * n * M; snd.rconc = b->d_rb + (id * (n + 1) + n) * M; snd.S_dev = b->d_nrules + id;
+        if ((rc = frirl_hip_merge_rb(&b->t, &master, &b->agent, b->d_rant, &snd, b->d_weights, nullptr, b->d_full, b->s))) return rc;
+    }
+    BCHK(hipMemcpyAsync(b->h_i.data(), b->d_nrules, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "nrules download");
+    BCHK(hipStreamSynchronize(b->s), "merge sync");
+    if (full_agents) for (size_t e = 0; e < E; e++) *full_agents += b->h_i[e] >= b->maxR;
+    // the merged rule bases are new starting points: the "same as the previous episode" test restarts from them (prev_* refreshed)
+    if ((rc = frirl_hip_convergence_refresh(&b->rb, b->nant, &b->conv, b->s))) return rc;
+    BCHK(hipStreamSynchronize(b->s), "merge sync");
+    return FRIRL_HIP_OK;
+}
+
+// frirl_omp_run's loop (frirl_agent.c:424-462) for the agents of this batch: rounds of `chunk - 1` episodes per agent
+// (FRIRL_AGENT_EPCHUNK = 10 in the reference's config.h.in:68), then one merge round, until the master's rule base is complete or
+// max_episodes - 1 episodes have run.
+extern "C" int frirl_hip_batch_train_merged(frirl_hip_batch *b, int32_t max_episodes, int32_t chunk, int32_t *episodes_run, int32_t *rounds)
+{
+    if (!b || chunk < 2) { set_error("frirl_hip_batch_train_merged: bad arguments"); return FRIRL_HIP_EINVAL; }
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    int ep = 1, nrounds = 0;
+    for (;;) {
+        int32_t master_done = 0;
+        for (int c = 1; c < chunk && ep < max_episodes; c++, ep++) {
+            const int rc = frirl_hip_batch_episode(b);
+            if (rc) return rc;
+            BCHK(hipMemcpy(&master_done, b->d_converged, sizeof(int32_t), hipMemcpyDeviceToHost), "converged download");
+            if (master_done) { ep++; break; }
+        }
+        if (master_done || ep >= max_episodes) break;
+        const int rc = frirl_hip_batch_merge_round(b, nullptr);
+        if (rc) return rc;
+        nrounds++;
+    }
+    if (episodes_run) *episodes_run = ep - 1;
+    if (rounds) *rounds = nrounds;
+    return FRIRL_HIP_OK;
 }
 
 // ---- batched rule-base I/O in the reference's .frirlrb.bin record format (frirl_utils.c:151-281) ------------------------

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void convergence_kernel(const double *__restri
                                                            const frirl_hip_convergence c, int init)
 {
     const int e = blockIdx.x;
-    if (!init && c.converged[e]) return;      // sticky: a completed rule base keeps its last report (workgroup-uniform)
+    if (init != 1 && c.converged[e]) return;      // sticky: a completed rule base keeps its last report (workgroup-uniform)
     const double *qcol = rb + ((size_t)e * (nant + 1) + nant) * maxR;
     double *prev = c.prev_rconc + (size_t)e * maxR;
     const int R = nrules[e];
@@ -534,7 +534,8 @@ __global__ __launch_bounds__(256) void convergence_kernel(const double *__restri
     for (int r = threadIdx.x; r < maxR; r += blockDim.x) prev[r] = qcol[r];                               // :72
     if (threadIdx.x == 0) {
         c.prev_nrules[e] = R;                                                                             // :68-70
-        if (init) { c.prev_steps[e] = -1; c.prev_reward[e] = -1.0; c.converged[e] = 0; c.episodes[e] = 0; }   // frirl_init.c:149-150
+        if (init == 1) { c.prev_steps[e] = -1; c.prev_reward[e] = -1.0; c.converged[e] = 0; c.episodes[e] = 0; }   // frirl_init.c:149-150
+        else if (init == 2) { c.prev_steps[e] = -1; c.prev_reward[e] = -1.0; }                                   // refresh after a merge
         else { c.prev_steps[e] = ev.ep_steps[e]; c.prev_reward[e] = ev.ep_reward[e]; }
     }
 }
@@ -744,6 +745,20 @@ extern "C" int frirl_hip_convergence_init(const frirl_hip_rulebases *b, int nant
     memset(&ev, 0, sizeof ev);
     hipLaunchKernelGGL(frirl::convergence_kernel, dim3(b->E), dim3(256), 0, as_stream(stream), b->rb, b->nrules, b->maxR, nant, ag, ev, *c, 1);
     return check_launch("frirl_hip_convergence_init");
+}
+
+// after the rule bases were changed from outside an episode (rule-base merge): the snapshot the next "same as the previous
+// episode" test compares with is retaken (rule count, consequents; previous steps / reward invalidated); converged agents keep theirs
+extern "C" int frirl_hip_convergence_refresh(const frirl_hip_rulebases *b, int nant, const frirl_hip_convergence *c, void *stream)
+{
+    int rc = check_convergence(b, c, "frirl_hip_convergence_refresh");
+    if (rc) return rc;
+    frirl_hip_agent ag;
+    frirl_hip_envs ev;
+    memset(&ag, 0, sizeof ag);
+    memset(&ev, 0, sizeof ev);
+    hipLaunchKernelGGL(frirl::convergence_kernel, dim3(b->E), dim3(256), 0, as_stream(stream), b->rb, b->nrules, b->maxR, nant, ag, ev, *c, 2);
+    return check_launch("frirl_hip_convergence_refresh");
 }
 
 extern "C" int frirl_hip_convergence_update(const frirl_hip_rulebases *b, int nant, const frirl_hip_agent *agent, const frirl_hip_envs *envs,

@@ -21,7 +21,7 @@ int main(int argc, char **argv)
     struct frirl_desc fr = frirl_desc_default;
     const char *env = "mountaincar";
     char name[128];
-    int i, max_episodes = 0, fargc = 0, reduce = 0, agents = 0, gpus = -1;
+    int i, max_episodes = 0, fargc = 0, reduce = 0, agents = 0, gpus = -1, merge = 0;
     const char *load_bin = NULL, *save_bin = NULL;
     char *fargv[16];
     fargv[fargc++] = argv[0];
@@ -30,12 +30,17 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--max-episodes") && i + 1 < argc) max_episodes = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--agents") && i + 1 < argc) agents = atoi(argv[++i]);      /* batched: N independent agents on the GPU */
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);          /* with --agents: shard over G devices (0 = all), RCCL report */
+        else if (!strcmp(argv[i], "--merge")) merge = 1;                                       /* with --agents: the agents exchange rule bases (frirl_omp_run) */
         else if (!strcmp(argv[i], "--load") && i + 1 < argc) load_bin = argv[++i];             /* batched: start from a .frirlrb.bin file */
         else if (!strcmp(argv[i], "--save") && i + 1 < argc) save_bin = argv[++i];             /* batched: all agents' rule bases to one .bin */
         else if (!strcmp(argv[i], "--reduce") && i + 1 < argc) reduce = atoi(argv[++i]);   /* construct, then reduce with strategy 1|2 */
         else if (fargc < 15) fargv[fargc++] = argv[i];
     }
     frirl_parse_cmdline(&fr, fargc, fargv);
+    if (agents > 0 && merge) {
+        snprintf(name, sizeof name, "%s.merged.frirlrb.txt", env);
+        return frirl_demo_merged_run(env, agents, max_episodes > 0 ? max_episodes : fr.max_episodes, name, 1) >= 0 ? 0 : 3;
+    }
     if (agents > 0 && gpus >= 0) {
         snprintf(name, sizeof name, "%s.multi.frirlrb.txt", env);
         return frirl_demo_multi_run(env, agents, gpus, max_episodes > 0 ? max_episodes : fr.max_episodes, name, 1) == agents ? 0 : 3;

@@ -351,6 +351,46 @@ int frirl_demo_multi_run(const char *env, int agents, int gpus, int max_episodes
     return (int)st.converged;
 }
 
+/* The reference's many-agent mode WITH the rule-base exchange (frirl_omp_run, frirl_agent.c:294-385 + :424-462) on one GPU: `agents`
+ * agents start from different states (gen_def_states), learn in chunks of FRIRL_AGENT_EPCHUNK - 1 = 9 episodes and merge their rule
+ * bases after every chunk (frirl_hip_batch_train_merged).  out_txt = the master's (agent 0's) rule base.  Returns the number of merge
+ * rounds, or -1. */
+int frirl_demo_merged_run(const char *env, int agents, int max_episodes, const char *out_txt, int verbose)
+{
+    int nant = 0, episodes = 0, rounds = 0, rc;
+    frirl_hip_batch_desc d;
+    struct demo_desc_mem mm;
+    frirl_hip_batch *b;
+    frirl_hip_batch_stats_t st;
+    double *start;
+    if (demo_desc_build(env, agents, &d, &mm, &nant) != 0) return -1;
+    start = malloc(sizeof(double) * (size_t)agents * (nant - 1));
+    if (!start || frirl_hip_gen_def_states(d.rant0, d.R0, nant, agents, d.agent.values_def, start) != 0) return -1;
+    d.start_states = start;
+    b = frirl_hip_batch_create(&d);
+    if (!b) five_dropin_fatal("frirl_demo_merged_run(create)", FRIRL_HIP_ENODEV);
+    rc = frirl_hip_batch_train_merged(b, max_episodes, 10, &episodes, &rounds);
+    if (rc) five_dropin_fatal("frirl_demo_merged_run(train)", rc);
+    rc = frirl_hip_batch_stats(b, &st);
+    if (rc) five_dropin_fatal("frirl_demo_merged_run(stats)", rc);
+    if (verbose)
+        printf("merged %s: agents %lld episodes %d merge-rounds %d converged %lld env-steps %lld mean-rules %.3f mean-reward %.6f\n", env, (long long)st.agents,
+               episodes, rounds, (long long)st.converged, (long long)st.total_env_steps, st.rules_sum / st.agents, st.reward_sum / st.agents);
+    if (st.full_agents > 0)
+        fprintf(stderr, "Warning: %lld of %lld rule bases are at their capacity of %d rules: further rule insertions were refused\n",
+                (long long)st.full_agents, (long long)st.agents, (int)d.maxR);
+    if (out_txt) {
+        int32_t R = 0;
+        double *rant = malloc(sizeof(double) * 1024 * nant), *rconc = malloc(sizeof(double) * 1024);
+        if (!rant || !rconc || frirl_hip_batch_get_rulebase(b, 0, &R, rant, rconc) != 0 || dump_rule_base_txt(out_txt, nant, R, rant, rconc) != 0) return -1;
+        free(rant); free(rconc);
+    }
+    frirl_hip_batch_destroy(b);
+    demo_desc_free(&mm);
+    free(start);
+    return rounds;
+}
+
 int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int reduce_strategy, const char *load_bin, const char *save_bin,
                             const char *out_txt, int verbose)
 {

@@ -30,6 +30,9 @@ int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int r
 
 /* `agents` agents over `gpus` devices of this node (0 = every visible device) through frirl_hip_multi_* (one batch + host thread per
  * device, per-episode report all-reduced with RCCL); out_txt = rule base of global agent 0.  Returns the converged agents or -1. */
+/* many agents WITH the reference's rule-base exchange (frirl_omp_run: chunks of 9 episodes, merge_rb in both directions after each,
+ * start states from gen_def_states) on one GPU; out_txt = the master's rule base.  Returns the number of merge rounds, or -1. */
+int frirl_demo_merged_run(const char *env, int agents, int max_episodes, const char *out_txt, int verbose);
 int frirl_demo_multi_run(const char *env, int agents, int gpus, int max_episodes, const char *out_txt, int verbose);
 
 #endif

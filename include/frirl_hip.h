@@ -331,6 +331,9 @@ int frirl_hip_episode_run(const frirl_hip_tables *t, const frirl_hip_rulebases *
 int frirl_hip_convergence_init(const frirl_hip_rulebases *b, int nant, const frirl_hip_convergence *c, void *stream);
 int frirl_hip_convergence_update(const frirl_hip_rulebases *b, int nant, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
                                  const frirl_hip_convergence *c, void *stream);
+/* after the rule bases were changed outside an episode (frirl_hip_merge_rb): retake the snapshot (rule count, consequents) the next
+ * convergence test compares with; converged agents keep theirs */
+int frirl_hip_convergence_refresh(const frirl_hip_rulebases *b, int nant, const frirl_hip_convergence *c, void *stream);
 
 /* ---- FIVEVagConcl_FRIRL_BestAct (reference src/five/FIVEVagConcl_FRIRL_BestAct.c:56-299) -------
  * Conclusion from PRECOMPUTED rule distances: first exact hit (d == 0) or Shepard interpolation.
@@ -436,6 +439,40 @@ int frirl_hip_batch_load_rulebases(frirl_hip_batch *b, const char *path, int32_t
 /* frirl_sequential_run's reduction phase (frirl_sequential_run.c:170-350) for agent e's rule base, in place, through
  * frirl_hip_reduce_shared (speculative batched try-remove); the other agents are untouched */
 int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strategy, double reward_tolerance, int depth, frirl_hip_reduce_result *result);
+/* One round of the reference's multi-agent rule-base exchange (frirl_omp_run, frirl_agent.c:426-462) inside the batch: every agent
+ * id >= 1 takes over the master's (agent 0's) rules -- all of them in one launch of frirl_hip_merge_rb --, then the master takes
+ * over the rules of agent 1, 2, ... in turn.  Agents whose rule base is complete do not send (:432,:444).  *full_agents (or NULL):
+ * agents at capacity afterwards.  Give the agents different start states (frirl_hip_gen_def_states -> desc.start_states). */
+int frirl_hip_batch_merge_round(frirl_hip_batch *b, int32_t *full_agents);
+/* frirl_omp_run's loop: rounds of chunk - 1 episodes per agent (the reference: FRIRL_AGENT_EPCHUNK = 10), a merge round after each,
+ * until the master's rule base is complete or max_episodes - 1 episodes have run */
+int frirl_hip_batch_train_merged(frirl_hip_batch *b, int32_t max_episodes, int32_t chunk, int32_t *episodes_run, int32_t *rounds);
+
+/* ---- multi-agent rule-base merge (reference src/frirl/frirl_agent.c:58-117 merge_rb, the body of its BUILD_OPENMP / BUILD_MPI
+ *      run modes) ----------------------------------------------------------------------------------------------
+ * Every receiver rule base e of the batch (active[e] != 0, or all) takes over the sender's S rules one after the other: with
+ * Qr = the receiver's conclusion at the sender rule's antecedents and Qs the sender's consequent, qdiff = Qs - Qr;
+ *   qdiff outside [qdiff_neg_boundary, qdiff_pos_boundary]: antecedents snapped to the receiver's rule grid; a free place gets a
+ *     NEW rule with 0.5 Q(snapped) + 0.5 Qs, an occupied one moves to 0.9 Q + 0.1 Qs;
+ *   else: every receiver rule with normalised Shepard weight > weight_significant is OVERWRITTEN with (0.9 Qr + 0.1 Qs) * weight
+ *     (the agent file's own update_rules, :45-53).  `weights` [dev][E][maxR] is the receivers' FIVERB.weights: it persists
+ *     between sender rules and calls (an exact hit leaves it untouched, FIVEVagConclWeight.c:67-69); zero it once.
+ * The sender rules are read as rant[r * rule_stride + k * dim_stride] (AoS like FIVERB.rant: rule_stride = nant, dim_stride = 1;
+ * a row set of frirl_hip_envs.rant: rule_stride = 1, dim_stride = maxR) and rconc[r]; S_dev != NULL: the count is read on the
+ * device (e.g. &nrules[sender]).  The sender must not be one of the active receivers.  full[e] = 1 when an append was refused. */
+typedef struct frirl_hip_sender {
+    const double *rant;         /* [dev] */
+    int64_t rule_stride, dim_stride;
+    const double *rconc;        /* [dev] [S] */
+    int32_t S;
+    int32_t reserved;
+    const int32_t *S_dev;       /* [dev] or NULL */
+} frirl_hip_sender;
+int frirl_hip_merge_rb(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, double *rant_store,
+                       const frirl_hip_sender *sender, double *weights, const uint8_t *active, int32_t *full, void *stream);
+/* gen_def_states (reference frirl_agent.c:121-139), HOST arrays: start_states[id][nant-1] for id < world from the master's rule list
+ * master_rant [R][nant] (AoS); agent 0 (and every agent when world < 3: the reference divides by world - 2) keeps values_def. */
+int frirl_hip_gen_def_states(const double *master_rant, int32_t R, int32_t nant, int32_t world, const double *values_def, double *start_states);
 
 /* =================================================================================================
  * Many agents over several GPUs of one node, from plain C (the reference's frirl_omp_run / frirl_mpi_run shape,

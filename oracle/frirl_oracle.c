@@ -812,7 +812,9 @@ int orc_gen_def_states(const orc_five *master, int id, int worldsize, int nstate
 {
     if (id == 0 || worldsize < 3) return 0;
     const int gap = master->R / (worldsize - 2);
-    for (int i = 0; i < nstates; i++) values_def[i] = master->rant[(size_t)(id - 1) * gap * master->nant + i];
+    size_t rule = (size_t)(id - 1) * gap;
+    if (rule >= (size_t)master->R) rule = (size_t)master->R - 1;   /* the reference reads one rule past its list for the last agent (uninitialised): last rule */
+    for (int i = 0; i < nstates; i++) values_def[i] = master->rant[rule * master->nant + i];
     return 1;
 }
 
