@@ -135,6 +135,13 @@ __device__ __forceinline__ double2 load_col2(const double *__restrict__ p)
     return v;
 }
 
+// the same without the non-temporal hint: for sweeps whose waves read the SAME columns (sweep_gba_wide: the action-parallel waves of a
+// workgroup) -- the first wave's line then serves the others from the CU's vector L1 / the XCD's L2 instead of going out four times
+__device__ __forceinline__ double2 load_col2_shared(const double *__restrict__ p)
+{
+    return *reinterpret_cast<const double2 *>(p);
+}
+
 // Antecedent-column accessors.  ColsF64 streams the f64 SoA columns (reference layout).  ColsIdx streams the 16-bit
 // universe indices (frirl_hip_rulebases.uidx) and reads the VE values from an LDS copy of the tables: the same
 // doubles (rb[k][r] == ve[k][uidx[k][r]] exactly), a quarter of the antecedent bytes.
@@ -144,6 +151,7 @@ struct ColsF64 {
     __device__ __forceinline__ double2 pair(int k, int r) const { return load_col2(base + (size_t)k * maxR + r); }
     using raw_t = double2;                 // raw()/decode(): the global load split from its use (software prefetch)
     __device__ __forceinline__ raw_t raw(int k, int r) const { return pair(k, r); }
+    __device__ __forceinline__ raw_t raw_shared(int k, int r) const { return load_col2_shared(base + (size_t)k * maxR + r); }
     __device__ __forceinline__ double2 decode(int, const raw_t &w) const { return w; }
 };
 
@@ -161,6 +169,7 @@ struct ColsIdx {
     }
     using raw_t = uint32_t;
     __device__ __forceinline__ raw_t raw(int k, int r) const { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(idx + (size_t)k * maxR + r)); }
+    __device__ __forceinline__ raw_t raw_shared(int k, int r) const { return *reinterpret_cast<const uint32_t *>(idx + (size_t)k * maxR + r); }
     __device__ __forceinline__ double2 decode(int k, raw_t w) const
     {
         double2 v;
@@ -177,6 +186,7 @@ struct ColsLds {
     __device__ __forceinline__ double2 pair(int k, int r) const { return *reinterpret_cast<const double2 *>(base + (size_t)k * cap + r); }
     using raw_t = double2;
     __device__ __forceinline__ raw_t raw(int k, int r) const { return pair(k, r); }
+    __device__ __forceinline__ raw_t raw_shared(int k, int r) const { return pair(k, r); }
     __device__ __forceinline__ double2 decode(int, const raw_t &w) const { return w; }
 };
 
@@ -595,6 +605,16 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     return s.best;
 }
 
+#ifndef FRIRL_WIDE_SYNC
+#define FRIRL_WIDE_SYNC 8
+#endif
+static constexpr int WIDE_SYNC = FRIRL_WIDE_SYNC;      // iterations between the barriers of sweep_gba_wide (0 = none; power of two)
+
+// (A branch-free form of the conclusion terms -- weight forced to 0 for exact hits / slots past the end instead of `if` -- was measured at
+//  cartpole's 21-action step: 2.73 -> 2.88 ms with the index store: the selects cost more VALU issue than the branches.  What did help:
+//  plain instead of non-temporal loads (the four action-parallel waves read the same lines: 84 % L1 hits), a barrier every 8 iterations
+//  that keeps the waves inside the L1 window, and 168 instead of 128 VGPRs (no spills; only three workgroups fit a CU beside 40 KB of
+//  tables anyway): 22.8 -> 19.9 ms per step of 32 768 x 32 768, f64 columns 6.4 -> 3.0 ms per 4096 environments; PMC: VALU busy 70 %.)
 // Many-action form of the greedy sweep (A > 8, e.g. cartpole's 21 actions).  Keeping A accumulator pairs per
 // lane costs ~250 VGPRs at A = 21 (one wave per SIMD, every dependent FP64 chain exposed).  Here the ACTIONS
 // are split over the waves of the workgroup instead: wave w evaluates actions [w*ag, (w+1)*ag) with
@@ -628,12 +648,15 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
     double2 nc = {0.0, 0.0};
     if (2 * lane < R) {
 #pragma unroll
-        for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, 2 * lane);
-        nc = load_col2(qcol + 2 * lane);
+        for (int k = 0; k < NANT; k++) nraw[k] = cols.raw_shared(k, 2 * lane);
+        nc = load_col2_shared(qcol + 2 * lane);
     }
     double T = 0.0;
     const int r_lim = (WITH_Q && TRACK) ? wave_uniform_limit(R) : R;      // see sweep_gba_q
     for (int r = 2 * lane; r < r_lim; r += 2 * FRIRL_WAVE, it++) {
+        // the waves read the same lines: a barrier every few iterations keeps them within the window the vector L1 still holds
+        // (trip count and `it` are the same for every wave of the workgroup)
+        if (WIDE_SYNC > 0 && (it & (WIDE_SYNC - 1)) == WIDE_SYNC - 1) __syncthreads();
         const bool live = !(WITH_Q && TRACK) || r < R;
         const bool second = (r + 1 < R);
         double2 v[NANT];
@@ -645,8 +668,8 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
             c = nc;
             if (r + 2 * FRIRL_WAVE < R) {
 #pragma unroll
-                for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * FRIRL_WAVE);
-                nc = load_col2(qcol + r + 2 * FRIRL_WAVE);
+                for (int k = 0; k < NANT; k++) nraw[k] = cols.raw_shared(k, r + 2 * FRIRL_WAVE);
+                nc = load_col2_shared(qcol + r + 2 * FRIRL_WAVE);
             }
 #pragma unroll
             for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);

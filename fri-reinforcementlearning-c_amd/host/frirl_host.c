@@ -394,59 +394,94 @@ static void frirl_reduce_rb(struct frirl_desc *frirl, double *prev_rconc, double
 /* reference src/frirl/frirl_sequential_run.c:24-355: incremental construction until the rule base, step count
  * and reward repeat and no consequent moved by >= qdiff_final_tolerance (:55-165), then the optional reduction
  * phase (:170-350). */
+/* what the construct loop remembers of the previous episode (:68-72) */
+struct episode_mark {
+    int rules, steps;
+    double reward;
+};
+
+static struct episode_mark mark_episode(const struct frirl_desc *frirl)
+{
+    struct episode_mark m;
+    m.rules = frirl->fiverb->numofrules;
+    m.steps = frirl->reward.ep_total_steps;
+    m.reward = frirl->reward.ep_total_value;
+    return m;
+}
+
+/* :83-87: the episode repeated the previous one (same rule count, steps and reward) and was a good one */
+static int episode_repeats(const struct frirl_desc *frirl, const struct episode_mark *before)
+{
+    const struct episode_mark now = mark_episode(frirl);
+    return before->rules == now.rules && before->steps == now.steps && now.reward > frirl->reward_good_above && before->reward == now.reward;
+}
+
+/* :134-148: 1 when no consequent moved by qdiff_final_tolerance or more since `old_rconc` (verbose: every mover is listed) */
+static int consequents_settled(const struct frirl_desc *frirl, const double *old_rconc)
+{
+    const struct FIVERB *frb = frirl->fiverb;
+    int settled = 1, r;
+    for (r = 0; r < frb->numofrules; r++) {
+        const double moved = frb->rconc[r] - old_rconc[r];
+        if (fabs(moved) < frirl->qdiff_final_tolerance) continue;
+        settled = 0;
+        if (frirl->verbose <= 0) break;
+        printf("Greater at rule %d. %.18f - %.18f = %.18f (max: %.18f)\n", r, frb->rconc[r], old_rconc[r], moved, frirl->qdiff_final_tolerance);
+    }
+    return settled;
+}
+
+static void report_episode(const struct frirl_desc *frirl)
+{
+    const double rew = frirl->reward.ep_total_value;
+    printf("#%d Episode: %d\tSteps: %d\tReward: %s%f%s\tRules: %d\n", frirl->agent_id, frirl->episode_num, frirl->reward.ep_total_steps,
+           rew > frirl->reward_good_above ? TERM_GREEN : TERM_RED, rew, TERM_NC, frirl->fiverb->numofrules);
+}
+
+/* the construct phase (:55-165); leaves the consequents / reward of the episode BEFORE the last one in old_rconc / *old_reward,
+ * which the reduction phase starts from */
+static void construct_rule_base(struct frirl_desc *frirl, double *old_rconc, double *old_reward)
+{
+    const size_t rconc_bytes = sizeof(double) * frirl->five_maxnumofrules;
+    const int agent_mode = frirl->runmode == FRIRL_MPI || frirl->runmode == FRIRL_OMP;
+    const int episode_budget = agent_mode ? FRIRL_AGENT_EPCHUNK : frirl->max_episodes;      /* at most budget - 1 episodes per call (:51,59) */
+    int done;
+    for (done = 1; done < episode_budget; done++) {
+        const struct episode_mark before = mark_episode(frirl);
+        int complete;
+        *old_reward = before.reward;
+        memcpy(old_rconc, frirl->fiverb->rconc, rconc_bytes);
+        frirl_episode(frirl);
+        report_episode(frirl);
+        complete = frirl->user_exited == 1;
+        if (!complete && episode_repeats(frirl, &before)) {
+            frirl->epended = 1;
+            if (frirl->verbose > 0) printf("Rule-base size and reward are the same as in the previous iteration.\n");
+            complete = consequents_settled(frirl, old_rconc);
+        } else if (complete) {
+            frirl->epended = 1;
+        }
+        if (complete) {
+            frirl->is_running = 0;
+            printf("-----------------------------------------------------------------\n");
+            printf("No more significant changes in rule-base. RB considered complete.\n");
+            printf("-----------------------------------------------------------------\n");
+            return;
+        }
+        frirl->episode_num++;
+    }
+    if (!(frirl->episode_num < (unsigned int)frirl->max_episodes)) frirl->is_running = 0;      /* budget used up (:60-62) */
+}
+
 void frirl_sequential_run(struct frirl_desc *frirl)
 {
-    struct FIVERB *frb = frirl->fiverb;
-    double *prev_rconc = MALLOC(sizeof(double) * frirl->five_maxnumofrules);
-    double prev_reward = frirl->reward.ep_total_value;
-    int epchunk = 1, i;
-    const int maxep = (frirl->runmode == FRIRL_MPI || frirl->runmode == FRIRL_OMP) ? FRIRL_AGENT_EPCHUNK : frirl->max_episodes;
+    double *old_rconc = MALLOC(sizeof(double) * frirl->five_maxnumofrules);
+    double old_reward = frirl->reward.ep_total_value;
     frirl->epended = 0;
-    memcpy(prev_rconc, frb->rconc, sizeof(double) * frirl->five_maxnumofrules);
-    if (frirl->construct_rb == 1) {
-        for (;;) {
-            int prev_numru, prev_steps, epend = 0;
-            if (!(epchunk < maxep)) {
-                if (!(frirl->episode_num < (unsigned int)frirl->max_episodes)) frirl->is_running = 0;
-                break;
-            }
-            prev_numru = frb->numofrules;
-            prev_reward = frirl->reward.ep_total_value;
-            prev_steps = frirl->reward.ep_total_steps;
-            memcpy(prev_rconc, frb->rconc, sizeof(double) * frirl->five_maxnumofrules);
-
-            frirl_episode(frirl);
-
-            printf("#%d Episode: %d\tSteps: %d\tReward: %s%f%s\tRules: %d\n", frirl->agent_id, frirl->episode_num, frirl->reward.ep_total_steps,
-                   frirl->reward.ep_total_value > frirl->reward_good_above ? TERM_GREEN : TERM_RED, frirl->reward.ep_total_value, TERM_NC,
-                   frb->numofrules);
-
-            if ((prev_numru == frb->numofrules && prev_steps == frirl->reward.ep_total_steps &&
-                 frirl->reward.ep_total_value > frirl->reward_good_above && prev_reward == frirl->reward.ep_total_value) || frirl->user_exited == 1) {
-                epend = 1;
-                frirl->epended = 1;
-                if (frirl->verbose > 0) printf("Rule-base size and reward are the same as in the previous iteration.\n");
-                for (i = 0; i < frb->numofrules; i++) {
-                    if (fabs(frb->rconc[i] - prev_rconc[i]) >= frirl->qdiff_final_tolerance) {
-                        epend = 0;
-                        if (frirl->verbose > 0) printf("Greater at rule %d. %.18f - %.18f = %.18f (max: %.18f)\n", i, frb->rconc[i], prev_rconc[i], frb->rconc[i] - prev_rconc[i], frirl->qdiff_final_tolerance);
-                        else break;
-                    }
-                }
-            }
-            if (epend == 1 || frirl->user_exited == 1) {
-                frirl->is_running = 0;
-                printf("-----------------------------------------------------------------\n");
-                printf("No more significant changes in rule-base. RB considered complete.\n");
-                printf("-----------------------------------------------------------------\n");
-                break;
-            }
-            frirl->episode_num++;
-            epchunk++;
-        }
-    }
-    if (frirl->reduce_rb == 1) frirl_reduce_rb(frirl, prev_rconc, prev_reward);
-    free(prev_rconc);
+    memcpy(old_rconc, frirl->fiverb->rconc, sizeof(double) * frirl->five_maxnumofrules);
+    if (frirl->construct_rb == 1) construct_rule_base(frirl, old_rconc, &old_reward);
+    if (frirl->reduce_rb == 1) frirl_reduce_rb(frirl, old_rconc, old_reward);
+    free(old_rconc);
 }
 
 /* reference src/frirl/frirl_agent.c:294-467: experimental OpenMP / MPI agent modes, off by default in
