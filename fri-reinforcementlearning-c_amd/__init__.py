@@ -638,9 +638,9 @@ def demo_batch(env, E, R, maxR, device, seed=0, max_steps=None, compressed=True,
     return prob, agent, envs
 
 
-def demo_agent(d, device, max_steps=None, **kw):
+def demo_agent(d, device, max_steps=None, p=0, **kw):
     return Agent(device, d["nant"], d["grids"], d["grid_div"], d["values_def"], d["action_ve"], d["alpha"], d["gamma"], d["qdiff_pos"],
-                 d["qdiff_neg"], d["weight_thr"], d["skip_rules"], 0, d["kind"], max_steps or d["max_steps"],
+                 d["qdiff_neg"], d["weight_thr"], d["skip_rules"], p, d["kind"], max_steps or d["max_steps"],
                  reward_good_above=d["reward_good_above"], qdiff_final_tolerance=d["qdiff_final_tolerance"], **kw)
 
 

@@ -178,3 +178,29 @@ def test_persistent_episode_kernel_keeps_the_index_mirror_in_sync(env):
     d_f64, h_f64 = plain.rule_distance(x)
     torch.cuda.synchronize()
     assert (h_idx == h_f64).all() and (d_idx[:, :R].view(torch.int64) == d_f64[:, :R].view(torch.int64)).all()
+
+
+def test_non_default_shepard_power_takes_the_per_environment_kernels():
+    """A Shepard power p != nant (the reference accepts any p, FIVEInit.c:89-93) is served by the per-environment kernels: train()
+    must not pick the lane-group kernel, and the LDS-persistent episode kernel (with its hand-off to the step kernel when the slab
+    fills: status FULL) must give exactly the bits of the plain step kernel."""
+    import torch
+    dev = torch.device("cuda", 0)
+
+    def run(persistent):
+        prob, agent, envs = frirl_amd.demo_fresh_batch("acrobot", 5, 1024, dev, p=2)
+        assert agent.desc.p == 2
+        conv = frirl_amd.train(prob, agent, envs, max_episodes=40, persistent=persistent, persistent_max_rules=1024)
+        torch.cuda.synchronize()
+        return prob, envs, conv
+
+    pa, ea, ca = run(True)
+    pb, eb, cb = run(False)
+    assert (pa.rb == pb.rb).all() and (pa.nrules == pb.nrules).all() and (pa.uidx == pb.uidx).all()
+    assert (ea.rant == eb.rant).all() and (ca.episodes == cb.episodes).all()
+    assert int(pa.nrules.max()) > 64, "the rule bases grew"
+    # and the lane-group entry point refuses the power instead of computing with the wrong one
+    with pytest.raises(frirl_amd.FrirlHipError):
+        prob, agent, envs = frirl_amd.demo_fresh_batch("acrobot", 5, 1024, dev, p=2)
+        frirl_amd.episode_begin(prob, agent, envs)
+        frirl_amd.episode_run_lanes(prob, agent, envs, 10)
