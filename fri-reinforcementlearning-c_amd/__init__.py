@@ -50,7 +50,8 @@ class AgentDesc(C.Structure):
 class EnvsDesc(C.Structure):
     """struct frirl_hip_envs (include/frirl_hip.h)."""
     _fields_ = [("states", C.c_void_p), ("q_ant", C.c_void_p), ("fus", C.c_void_p), ("done", C.c_void_p), ("ep_steps", C.c_void_p),
-                ("ep_reward", C.c_void_p), ("rant", C.c_void_p), ("status", C.c_void_p), ("start_states", C.c_void_p), ("episode", C.c_void_p)]
+                ("ep_reward", C.c_void_p), ("rant", C.c_void_p), ("status", C.c_void_p), ("start_states", C.c_void_p), ("episode", C.c_void_p),
+                ("spread_ant", C.c_void_p), ("spread_R", C.c_void_p)]
 
 
 class RolloutDesc(C.Structure):
@@ -134,6 +135,7 @@ SIGNATURES = {
     "frirl_hip_batch_train_merged": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "frirl_hip_merge_rb": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.c_void_p, C.POINTER(SenderDesc), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frirl_hip_weights_from_spread": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_int, C.POINTER(EnvsDesc), C.c_void_p, C.c_void_p]),
     "frirl_hip_gen_def_states": (C.c_int, [_DP, C.c_int32, C.c_int32, C.c_int32, _DP, _DP]),
     # several GPUs from plain C (one batch + host thread per device, RCCL all-reduce of the report)
     "frirl_hip_shard": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -406,9 +408,12 @@ class Envs:
         self.rant = None
         if keep_rant:
             self.rant = torch.zeros((E, nant, maxR), dtype=torch.float64, device=device) if rant_init is None else rant_init
+        self.spread_ant = torch.zeros((E, nant), dtype=torch.float64, device=device)     # what determines FIVERB.weights after learning
+        self.spread_R = torch.zeros((E,), dtype=torch.int32, device=device)
         self.desc = EnvsDesc(self.states.data_ptr(), self.q_ant.data_ptr(), self.fus.data_ptr(), self.done.data_ptr(), self.ep_steps.data_ptr(),
                              self.ep_reward.data_ptr(), self.rant.data_ptr() if self.rant is not None else None, self.status.data_ptr(),
-                             self.start_states.data_ptr() if self.start_states is not None else None, self.episode.data_ptr())
+                             self.start_states.data_ptr() if self.start_states is not None else None, self.episode.data_ptr(),
+                             self.spread_ant.data_ptr(), self.spread_R.data_ptr())
 
 
 def update_sarsa(problem, agent, envs, q_ant, reward, cur_q_ant, active=None, stream=None):
@@ -534,7 +539,7 @@ def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=No
     conv = Convergence(problem, problem.rb.device)
     max_steps = agent.desc.max_steps
     if lanes is None:           # lane-group kernel where it is the faster form (many agents / small rule bases)
-        lanes = bool(lib().frirl_hip_lanes_preferred(problem.nant, problem.E, agent.A)) and agent.desc.p in (0, problem.nant)
+        lanes = bool(lib().frirl_hip_lanes_preferred(problem.nant, problem.E, agent.A))
     for ep in range(1, max_episodes):
         episode_begin(problem, agent, envs)
         envs.done.copy_(torch.maximum(envs.done, conv.converged))       # converged agents sit this episode out

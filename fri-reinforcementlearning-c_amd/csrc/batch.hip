@@ -20,6 +20,8 @@ struct frirl_hip_batch {
     double *d_weights;           // [E][maxR] FIVERB.weights of every agent (rule-base merge; allocated on first use)
     uint8_t *d_active;           // [E] receiver mask of a merge round
     int32_t *d_full;             // [E] append refused during a merge
+    double *d_spread_ant;        // [E][nant] / [E]: what determines FIVERB.weights after learning (frirl_hip_envs.spread_*)
+    int32_t *d_spread_R;
     void *d_lanes_ws;            // transposed rule bases of the lane-group kernel (allocated on first use)
     size_t lanes_ws_bytes;
     int32_t *d_nrules, *d_fus, *d_done, *d_ep_steps, *d_status, *d_episode, *d_prev_nrules, *d_prev_steps, *d_converged, *d_episodes;
@@ -73,7 +75,7 @@ extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
     if (b->s) (void)hipStreamSynchronize(b->s);
     void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
                     b->d_prev_rconc, b->d_tmp, b->d_nrules, b->d_fus, b->d_done, b->d_ep_steps, b->d_status, b->d_episode, b->d_prev_nrules,
-                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_uidx, b->d_lanes_ws, b->d_weights, b->d_active, b->d_full};
+                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_uidx, b->d_lanes_ws, b->d_weights, b->d_active, b->d_full, b->d_spread_ant, b->d_spread_R};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->s) (void)hipStreamDestroy(b->s);
     delete b;
@@ -95,7 +97,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
     ok = ok && dalloc(&b->d_states, E * ns) && dalloc(&b->d_q_ant, E * n) && dalloc(&b->d_ep_reward, E) && dalloc(&b->d_prev_reward, E);
     ok = ok && dalloc(&b->d_prev_rconc, E * M) && dalloc(&b->d_tmp, E * (n + 1)) && dalloc(&b->d_nrules, E) && dalloc(&b->d_fus, E) && dalloc(&b->d_done, E);
     ok = ok && dalloc(&b->d_ep_steps, E) && dalloc(&b->d_status, E) && dalloc(&b->d_episode, E) && dalloc(&b->d_prev_nrules, E) && dalloc(&b->d_prev_steps, E);
-    ok = ok && dalloc(&b->d_converged, E) && dalloc(&b->d_episodes, E + 1);
+    ok = ok && dalloc(&b->d_converged, E) && dalloc(&b->d_episodes, E + 1) && dalloc(&b->d_spread_ant, E * n) && dalloc(&b->d_spread_R, E);
     if (ok && d->U <= 65536) ok = dalloc(&b->d_uidx, E * n * M);
     if (ok && d->start_states) ok = dalloc(&b->d_start, E * ns) && hipMemcpy(b->d_start, d->start_states, sizeof(double) * E * ns, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(b->d_u, d->u, sizeof(double) * n * d->U, hipMemcpyHostToDevice) == hipSuccess;
@@ -111,6 +113,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
     memset(&b->envs, 0, sizeof b->envs);
     b->envs.states = b->d_states; b->envs.q_ant = b->d_q_ant; b->envs.fus = b->d_fus; b->envs.done = b->d_done; b->envs.ep_steps = b->d_ep_steps;
     b->envs.ep_reward = b->d_ep_reward; b->envs.rant = b->d_rant; b->envs.status = b->d_status; b->envs.start_states = b->d_start; b->envs.episode = b->d_episode;
+    b->envs.spread_ant = b->d_spread_ant; b->envs.spread_R = b->d_spread_R;
     b->conv.prev_nrules = b->d_prev_nrules; b->conv.prev_steps = b->d_prev_steps; b->conv.prev_reward = b->d_prev_reward; b->conv.prev_rconc = b->d_prev_rconc;
     b->conv.converged = b->d_converged; b->conv.episodes = b->d_episodes;
     b->total_env_steps = 0;
@@ -142,7 +145,7 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
     const int chunk = 64;
     int32_t running = 1;
     // many agents / small rule bases: lane-group kernel, the whole episode in one launch (frirl_hip_episode_run_lanes)
-    if (frirl_hip_lanes_preferred(b->nant, b->E, b->agent.A) && (b->agent.p <= 0 || b->agent.p == b->nant)) {
+    if (frirl_hip_lanes_preferred(b->nant, b->E, b->agent.A)) {
         if (!b->d_lanes_ws) {
             b->lanes_ws_bytes = frirl_hip_lanes_workspace_bytes(b->nant, b->E, b->maxR, b->agent.A);
             BCHK(hipMalloc(&b->d_lanes_ws, b->lanes_ws_bytes), "lane-group workspace");
@@ -278,6 +281,8 @@ extern "C" int frirl_hip_batch_merge_round(frirl_hip_batch *b, int32_t *full_age
     BCHK(hipStreamSynchronize(b->s), "merge sync");
     std::vector<int32_t> conv(b->h_i.begin(), b->h_i.begin() + E);
     int rc;
+    // the receivers' FIVERB.weights as the learning episodes left them (the reference's merge starts from that array)
+    if ((rc = frirl_hip_weights_from_spread(&b->t, &b->rb, b->agent.p, &b->envs, b->d_weights, b->s))) return rc;
     frirl_hip_sender snd;
     memset(&snd, 0, sizeof snd);
     snd.rule_stride = 1; snd.dim_stride = (int64_t)M;

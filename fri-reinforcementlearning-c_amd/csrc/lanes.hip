@@ -220,8 +220,8 @@ struct LaneQ {              // one conclusion's raw result
 };
 
 // FIVE_vag_concl's sums for one VE point, all rules, on one lane (sequential, rule order)
-template <int NANT, class STORE>
-__device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const double (&q)[NANT], int p)
+template <int NANT, class STORE, class POW>
+__device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const double (&q)[NANT], POW p)
 {
     LaneQ o{0.0, 0.0, FRIRL_HIP_NO_HIT};
     for_rules<true, NANT>(st, 0, 1, R, [&](int r, const double (&c)[NANT + 1]) {
@@ -230,7 +230,7 @@ __device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const doub
 #pragma unroll
         for (int k = 1; k < NANT; k++) { const double d = q[k] - c[k]; s = __fma_rn(d, d, s); }
         if (s == 0.0) { if (o.hit == FRIRL_HIP_NO_HIT) o.hit = (unsigned)r; }
-        else { const double wi = shepard_w(s, PowC<NANT>()); o.v = __fma_rn(wi, c[NANT], o.v); o.w = o.w + wi; }
+        else { const double wi = shepard_w(s, p); o.v = __fma_rn(wi, c[NANT], o.v); o.w = o.w + wi; }
     });
     return o;
 }
@@ -250,7 +250,9 @@ struct LanesArgs {
 
 // One wave = 64/G environments.  APL = conclusions per lane: lanes 0..G-2 hold APL actions each ((G-1)*APL >= A), lane
 // G-1 holds Q(s,a).
-template <int NANT, int APL, int G, int H, int WPE, bool IDX>
+// PN: the Shepard power is the default p = nant as a compile-time constant (PowC<NANT>: every demo and BASELINE shape); else the
+// run-time power of the agent (PowU; instantiated without rule slices only)
+template <int NANT, int APL, int G, int H, int WPE, bool IDX, bool PN = true>
 __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const LanesArgs la, const frirl_hip_agent ag, const frirl_hip_envs ev, int nsteps)
 {
     constexpr int NS = NANT - 1, GH = G * H, EPW = FRIRL_WAVE / GH;
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
         st.maxR = maxR;
         st.EPW = EPW;
     }
-    const int p = NANT;                  // the Shepard power is the default p = nant (checked by the host): compile-time PowC<NANT>
+    using POW = typename std::conditional<PN, PowC<NANT>, PowU>::type;
+    POW p;
+    if constexpr (!PN) p.p = ag.p > 0 ? ag.p : NANT;
     const bool has_q = (sub == G - 1);
 
     double states[NS], q_ant[NANT], total = 0.0;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                         const double ea = apt[i] - va;
                         const double d2 = __fma_rn(ea, ea, s);
                         if (d2 == 0.0) { if (hit[i] == FRIRL_HIP_NO_HIT) hit[i] = (unsigned)r; }
-                        else { const double wi = shepard_w(d2, PowC<NANT>()); sv[i] = __fma_rn(wi, cq, sv[i]); sw[i] = sw[i] + wi; }
+                        else { const double wi = shepard_w(d2, p); sv[i] = __fma_rn(wi, cq, sv[i]); sw[i] = sw[i] + wi; }
                     }
                 }
             });
@@ -444,13 +448,18 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                     } else {
                         if (ag.skip_rules == 0) fus = 0;                                                // :70-73
                         const int r_skip = fus ? R - 1 : -1;                                            // :76,124-126
+                        if (hit1 == FRIRL_HIP_NO_HIT && gl == 0 && ev.spread_ant) {     // this call defines FIVERB.weights from now on (frirl_hip.h)
+#pragma unroll
+                            for (int k = 0; k < NANT; k++) ev.spread_ant[(size_t)e * NANT + k] = q_ant[k];
+                            if (ev.spread_R) ev.spread_R[e] = R;
+                        }
                         const double iws = 1.0 / ws1;
                         for_rules<false, NANT>(st, gl, GH, R, [&](int r, const double (&c)[NANT + 1]) {   // K6 + K7, rules split over the group
                             const double d0 = ve1[0] - c[0];
                             double s = d0 * d0;
 #pragma unroll
                             for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; s = __fma_rn(d, d, s); }
-                            const double w = shepard_w(s, PowC<NANT>()) * iws;
+                            const double w = shepard_w(s, p) * iws;
                             if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; *st.qptr(r) = qnow + t; }
                         });
                         status = FRIRL_HIP_UPD_SPREAD;
@@ -515,7 +524,7 @@ extern "C" int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A)
     return 1;
 }
 
-template <int N, int APL, int G, int H, bool IDX>
+template <int N, int APL, int G, int H, bool IDX, bool PN = true>
 static void launch_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev, int nsteps,
                          void *T, hipStream_t s)
 {
@@ -539,8 +548,9 @@ static void launch_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b
     const int blocks = (la.tiles + frirl::LN_WPB - 1) / frirl::LN_WPB;
     int wpe = (la.tiles > 2048 && N <= 3) ? 4 : 2;
     { const int v = frirl_host::opts().lanes_wpe; if (v == 2 || v == 4) wpe = v; }
-#define LANES_GO(WPE) hipLaunchKernelGGL((frirl::episode_run_lanes_kernel<N, APL, G, H, WPE, IDX>), dim3(blocks), dim3(frirl::LN_BLOCK), dyn, s, la, *ag, *ev, nsteps)
-    if (wpe == 4) LANES_GO(4); else LANES_GO(2);
+#define LANES_GO(WPE) hipLaunchKernelGGL((frirl::episode_run_lanes_kernel<N, APL, G, H, WPE, IDX, PN>), dim3(blocks), dim3(frirl::LN_BLOCK), dyn, s, la, *ag, *ev, nsteps)
+    if constexpr (!PN) { (void)wpe; LANES_GO(2); }
+    else { if (wpe == 4) LANES_GO(4); else LANES_GO(2); }
 #undef LANES_GO
     if (IDX)          // antecedents of appended rules were written through; only the consequents come back
         hipLaunchKernelGGL(frirl::lanes_export_kernel, dim3(la.tiles, 1), dim3(256), 0, s, b->rb, b->nrules, b->E, N + 1, b->maxR, EPW,
@@ -556,11 +566,7 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     int rc = frirl_check_episode(t, b, agent, envs, "frirl_hip_episode_run_lanes");
     if (rc) return rc;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) { set_error("frirl_hip_episode_run_lanes: workspace must be 16-byte aligned"); return FRIRL_HIP_EINVAL; }
-    if (agent->p > 0 && agent->p != t->nant) {
-        set_error("frirl_hip_episode_run_lanes: the lane-group kernels are built for the default Shepard power p = nant (got p=%d, nant=%d); "
-                  "use frirl_hip_episode_steps", agent->p, t->nant);
-        return FRIRL_HIP_EINVAL;
-    }
+    const bool pn = agent->p <= 0 || agent->p == t->nant;      // default Shepard power: compile-time constant in the kernels
     if (nsteps < 0 || !workspace) { set_error("frirl_hip_episode_run_lanes: nsteps=%d / workspace=%p", nsteps, workspace); return FRIRL_HIP_EINVAL; }
     const size_t need = frirl_hip_lanes_workspace_bytes(t->nant, b->E, b->maxR, agent->A);
     if (workspace_bytes < need) { set_error("frirl_hip_episode_run_lanes: workspace %zu B < %zu B (frirl_hip_lanes_workspace_bytes)", workspace_bytes, need); return FRIRL_HIP_EINVAL; }
@@ -569,7 +575,14 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     // index store when the caller keeps the 16-bit index mirror and the VE tables fit in LDS (48 KiB)
     bool idx = b->uidx != nullptr && sizeof(double) * t->nant * (size_t)t->U <= 48 * 1024 && t->U <= 65536;
     if (frirl_host::opts().no_uidx == 1) idx = false;
-    const int H = lanes_slices(b->E, agent->A);
+    const int H = pn ? lanes_slices(b->E, agent->A) : 1;       // run-time power: the variants without rule slices
+#define RUN2P(N, IDX)                                                                                 \
+    do {                                                                                              \
+        if (G == 4) launch_lanes<N, 1, 4, 1, IDX, false>(t, b, agent, envs, nsteps, workspace, s);    \
+        else if (apl == 1) launch_lanes<N, 1, 8, 1, IDX, false>(t, b, agent, envs, nsteps, workspace, s); \
+        else if (apl == 3) launch_lanes<N, 3, 8, 1, IDX, false>(t, b, agent, envs, nsteps, workspace, s); \
+        else launch_lanes<N, 5, 8, 1, IDX, false>(t, b, agent, envs, nsteps, workspace, s);           \
+    } while (0)
 #define RUN2(N, IDX, HH)                                                                              \
     do {                                                                                              \
         if (G == 4) launch_lanes<N, 1, 4, HH, IDX>(t, b, agent, envs, nsteps, workspace, s);          \
@@ -581,9 +594,13 @@ extern "C" int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frir
     do {                                                                       \
         if (H == 8) RUN2(N, IDX, 8); else if (H == 4) RUN2(N, IDX, 4); else if (H == 2) RUN2(N, IDX, 2); else RUN2(N, IDX, 1); \
     } while (0)
-    if (t->nant == 3) { if (idx) RUN(3, true); else RUN(3, false); }
+    if (!pn) {
+        if (t->nant == 3) { if (idx) RUN2P(3, true); else RUN2P(3, false); }
+        else { if (idx) RUN2P(5, true); else RUN2P(5, false); }
+    } else if (t->nant == 3) { if (idx) RUN(3, true); else RUN(3, false); }
     else { if (idx) RUN(5, true); else RUN(5, false); }
 #undef RUN
 #undef RUN2
+#undef RUN2P
     return check_launch("frirl_hip_episode_run_lanes");
 }

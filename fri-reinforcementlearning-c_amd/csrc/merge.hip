@@ -119,9 +119,53 @@ __global__ __launch_bounds__(BLOCK) void merge_rb_kernel(const double *__restric
     }
 }
 
+// FIVERB.weights as the learning loop left it (frirl_hip.h: frirl_hip_weights_from_spread)
+template <int NANT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void weights_from_spread_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U, const double *__restrict__ rb,
+                                                                     int maxR, int p, const double *__restrict__ spread_ant, int32_t *__restrict__ spread_R,
+                                                                     double *__restrict__ weights)
+{
+    const int e = blockIdx.x;
+    const int R = spread_R[e];
+    if (R <= 0) return;          // workgroup-uniform
+    __shared__ double q_s[NANT];
+    __shared__ BlockRed<BLOCK> red;
+    if (threadIdx.x < NANT) q_s[threadIdx.x] = observe_ve(u, ve, U, threadIdx.x, spread_ant[(size_t)e * NANT + threadIdx.x]);
+    __syncthreads();
+    double q[NANT];
+#pragma unroll
+    for (int k = 0; k < NANT; k++) q[k] = q_s[k];
+    const double *base = rb + (size_t)e * (NANT + 1) * maxR;
+    const ColsF64 cols{base, maxR};
+    const QResult rn = sweep_q<NANT, BLOCK>(cols, base + (size_t)NANT * maxR, R, q, p, red);
+    if (rn.hit == FRIRL_HIP_NO_HIT) sweep_weights<NANT, BLOCK>(cols, R, q, p, rn.ws, weights + (size_t)e * maxR);
+    __syncthreads();
+    if (threadIdx.x == 0) spread_R[e] = 0;
+}
+
 }  // namespace frirl
 
 using namespace frirl_host;
+
+extern "C" int frirl_hip_weights_from_spread(const frirl_hip_tables *t, const frirl_hip_rulebases *b, int p, const frirl_hip_envs *envs, double *weights, void *stream)
+{
+    int rc = check_rulebases(t, b);
+    if (rc) return rc;
+    if (!envs || !envs->spread_ant || !envs->spread_R || !weights) { set_error("frirl_hip_weights_from_spread: NULL argument (envs->spread_ant / spread_R / weights)"); return FRIRL_HIP_EINVAL; }
+    if ((rc = check_device())) return rc;
+    const int pp = p > 0 ? p : t->nant;
+    switch (t->nant) {
+#define M(N)                                                                                                                              \
+    case N:                                                                                                                               \
+        hipLaunchKernelGGL((frirl::weights_from_spread_kernel<N, 256>), dim3(b->E), dim3(256), 0, as_stream(stream), t->u, t->ve, t->U, b->rb, b->maxR, pp, \
+                           envs->spread_ant, envs->spread_R, weights);                                                                    \
+        break;
+        M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+#undef M
+        default: set_error("frirl_hip_weights_from_spread: nant=%d outside 2..9", t->nant); return FRIRL_HIP_EINVAL;
+    }
+    return check_launch("frirl_hip_weights_from_spread");
+}
 
 extern "C" int frirl_hip_merge_rb(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, double *rant_store,
                                   const frirl_hip_sender *sender, double *weights, const uint8_t *active, int32_t *full, void *stream)

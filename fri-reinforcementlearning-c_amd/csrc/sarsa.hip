@@ -35,7 +35,7 @@ template <int NANT, int BLOCK, bool TRACK = false, class COLS, class POW>
 __device__ int update_sarsa_block(const COLS &cols, const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ base,
                                   int maxR, int32_t *nrules_e, const frirl_hip_agent &ag, StepShared &sh, double reward,
                                   bool qp_known, double qp, int32_t *fus_e, double *rant_e, BlockRed<BLOCK> &red,
-                                  const QResult *rn_known, uint16_t *uidx_e, POW p, SpreadCand *slot)
+                                  const QResult *rn_known, uint16_t *uidx_e, POW p, SpreadCand *slot, double *spread_ant_e = nullptr, int32_t *spread_R_e = nullptr)
 {
     const int R = *nrules_e;
     double q1[NANT], q2[NANT];
@@ -101,6 +101,10 @@ __device__ int update_sarsa_block(const COLS &cols, const double *__restrict__ u
     } else {
         if (ag.skip_rules == 0) fus = 0;                                    // :70-73
         const int r_skip = fus ? R - 1 : -1;                                // :76,124-126: the just-inserted rule keeps its Q
+        if (rn.hit == FRIRL_HIP_NO_HIT) {      // FIVE_vag_concl_weight interpolated (:40): this call defines FIVERB.weights from now on
+            if (spread_ant_e && threadIdx.x < NANT) spread_ant_e[threadIdx.x] = sh.q_ant[threadIdx.x];
+            if (spread_R_e && threadIdx.x == 0) *spread_R_e = R;
+        }
         // K6+K7: from the candidates tracked during the Q(s,a) sweep when possible (no second pass over the slab), else the sweep
         const bool from_cand = TRACK && rn.tracked && rn.hit == FRIRL_HIP_NO_HIT && !frirl_no_spread_candidates(ag) &&
                                spread_from_candidates<BLOCK>(slot[threadIdx.x], qcol, rn.ws, qnow, qdiff, ag.weight_significant, r_skip, red);
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(BLOCK) void update_sarsa_kernel(const double *__res
     uint16_t *uidx_e = uidx ? uidx + (size_t)e * NANT * maxR : nullptr;
     const auto cols = ColsSel<IDX>::make(base, uidx_e, tab_s, maxR, U);
     const int st = update_sarsa_block<NANT, BLOCK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, reward[e], false, 0.0, ev.fus + e, rant_e, red, nullptr, uidx_e,
-                                                   ag.p > 0 ? ag.p : NANT, nullptr);
+                                                   ag.p > 0 ? ag.p : NANT, nullptr,
+                                                   ev.spread_ant ? ev.spread_ant + (size_t)e * NANT : nullptr, ev.spread_R ? ev.spread_R + e : nullptr);
     if (threadIdx.x == 0 && ev.status) ev.status[e] = st;
 }
 
@@ -306,7 +311,8 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     double *rant_e = ev.rant ? ev.rant + (size_t)e * NANT * maxR : nullptr;
     int st = FRIRL_HIP_UPD_INACTIVE;
     if (!ag.evaluate)                                                                                 // :155 (reduction_state == 0)
-        st = update_sarsa_block<NANT, BLOCK, TRACK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn, uidx_e, pw, cand_s);  // :159
+        st = update_sarsa_block<NANT, BLOCK, TRACK>(cols, u, ve, U, base, maxR, nrules + e, ag, sh, sh.reward, true, qp, ev.fus + e, rant_e, red, &rn, uidx_e, pw, cand_s,
+                                                    ev.spread_ant ? ev.spread_ant + (size_t)e * NANT : nullptr, ev.spread_R ? ev.spread_R + e : nullptr);  // :159
     if (threadIdx.x < NS) ev.states[(size_t)e * NS + threadIdx.x] = sh.cur_states[threadIdx.x];      // :163-165
     if (threadIdx.x < NANT) ev.q_ant[(size_t)e * NANT + threadIdx.x] = sh.cur_q_ant[threadIdx.x];    // :166-168
     if (threadIdx.x == 0) {
@@ -401,7 +407,8 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
         __syncthreads();
         const double qp = gs.actconc[gs.best];
         int st = FRIRL_HIP_UPD_INACTIVE;
-        if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr, p, nullptr);
+        if (!ag.evaluate) st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, CAP, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr, p, nullptr,
+                                                                    ev.spread_ant ? ev.spread_ant + (size_t)e * NANT : nullptr, ev.spread_R ? ev.spread_R + e : nullptr);
         __syncthreads();
         if (st == FRIRL_HIP_UPD_INSERTED && threadIdx.x < NANT) {
             if (rant_e) rant_e[(size_t)threadIdx.x * maxR + (nrules_s - 1)] = sh.rant[threadIdx.x];

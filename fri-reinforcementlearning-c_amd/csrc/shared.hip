@@ -186,7 +186,8 @@ __device__ __forceinline__ void group_first_max(double &bv, int &bi)
 // rule base stays read-only and can be shared.  G consecutive lanes serve one environment, each evaluating its own
 // block of actions (G = 1 for throughput when Q fills the chip; G = 4 / 8 cut the per-step latency when Q is small, the
 // case of the reduction's replays); the environment state is kept redundantly by all G lanes.
-template <int NANT, int AMAX, int G, int H, bool EXCL>
+// PN: Shepard power = the default nant as a compile-time constant; else the agent's run-time power (instantiated without rule slices)
+template <int NANT, int AMAX, int G, int H, bool EXCL, bool PN = true>
 __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                                    const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
                                                                    const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro)
@@ -198,7 +199,9 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
     const int qi = blockIdx.x * EPB + threadIdx.x / GH;
     const bool exists = qi < Q;
     const int R = nrules[0];
-    const PowC<NANT> p;                                              // default Shepard power p = nant (checked by the host)
+    using POW = typename std::conditional<PN, PowC<NANT>, PowU>::type;
+    POW p;
+    if constexpr (!PN) p.p = ag.p > 0 ? ag.p : NANT;
     const int apl = (ag.A + G - 1) / G;                              // actions per lane
     const int abeg = (sub * apl < ag.A) ? sub * apl : ag.A;
     const int aend = (abeg + apl < ag.A) ? abeg + apl : ag.A;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
     unsigned h0;
     int a;
     double bv;
-    shared_sweep<NANT, AMAX, true, EXCL, G, H, PowC<NANT>>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, exists, mask, nullptr, h0, a, bv, h);   // :78 (un-quantised start state)
+    shared_sweep<NANT, AMAX, true, EXCL, G, H, POW>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, exists, mask, nullptr, h0, a, bv, h);   // :78 (un-quantised start state)
     group_first_max<G>(bv, a);
     a = e_greedy(ag, a, (uint32_t)qi, 0u, 0u);
     double action = grid_s[NS * FRIRL_HIP_MAX_GRID + a];                                                 // :82
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *
             for (int k = 0; k < NS; k++) q[k] = observe_ve(u, ve, U, k, qs[k]);
         }
         int pa;
-        shared_sweep<NANT, AMAX, true, EXCL, G, H, PowC<NANT>>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, active, mask, nullptr, h0, pa, bv, h);   // :148
+        shared_sweep<NANT, AMAX, true, EXCL, G, H, POW>(tl, rb, ro.rule_slot, R, maxR, p, abeg, aend, nchunks, q, active, mask, nullptr, h0, pa, bv, h);   // :148
         group_first_max<G>(bv, pa);
         if (active) {
             pa = e_greedy(ag, pa, (uint32_t)qi, 0u, (uint32_t)step);
@@ -306,16 +309,16 @@ extern "C" int frirl_hip_get_best_action_shared(const frirl_hip_tables *t, const
     return check_launch("frirl_hip_get_best_action_shared");
 }
 
-template <int N, int AMAX, int G, int H>
+template <int N, int AMAX, int G, int H, bool PN = true>
 static void launch_rollout(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
                            hipStream_t s)
 {
     constexpr int EPB = frirl::SH_BLOCK / (G * H);
     const dim3 grid((Q + EPB - 1) / EPB);
     if (ro->exclude_mask && ro->rule_slot)
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, true>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, true, PN>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
     else
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, false>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, false, PN>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
 }
 
 // lanes per environment: 1 once the environments alone fill the chip, else split the actions over 4 (A <= 4) or 8 lanes
@@ -351,6 +354,13 @@ static void launch_rollout_n(const frirl_hip_tables *t, const frirl_hip_rulebase
                              hipStream_t s)
 {
     const int G = rollout_group(Q, ag->A);
+    if (ag->p > 0 && ag->p != N) {          // run-time Shepard power: the variants without rule slices
+        if (G == 4) launch_rollout<N, 1, 4, 1, false>(t, b, ag, Q, ro, s);
+        else if (G == 8) launch_rollout<N, 4, 8, 1, false>(t, b, ag, Q, ro, s);
+        else if (ag->A <= 4) launch_rollout<N, 4, 1, 1, false>(t, b, ag, Q, ro, s);
+        else launch_rollout<N, 8, 1, 1, false>(t, b, ag, Q, ro, s);
+        return;
+    }
     if (G == 4) launch_rollout_h<N, 1, 4>(t, b, ag, Q, ro, s);
     else if (G == 8) launch_rollout_h<N, 4, 8>(t, b, ag, Q, ro, s);
     else if (ag->A <= 4) launch_rollout<N, 4, 1, 1>(t, b, ag, Q, ro, s);
@@ -364,11 +374,6 @@ extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_h
     if (rc) return rc;
     if (!agent || !ro || !ro->steps || !ro->reward || !agent->grid_values || !agent->action_ve) { set_error("frirl_hip_rollout_shared: NULL argument"); return FRIRL_HIP_EINVAL; }
     if (agent->A < 1 || agent->A > FRIRL_HIP_MAX_ACTIONS || agent->max_steps < 0) { set_error("frirl_hip_rollout_shared: A=%d / max_steps=%d out of range", agent->A, agent->max_steps); return FRIRL_HIP_EINVAL; }
-    if (agent->p > 0 && agent->p != t->nant) {
-        set_error("frirl_hip_rollout_shared: built for the default Shepard power p = nant (got p=%d, nant=%d); use frirl_hip_episode_steps with "
-                  "agent->evaluate = 1", agent->p, t->nant);
-        return FRIRL_HIP_EINVAL;
-    }
     for (int k = 0; k < t->nant; k++)
         if (agent->grid_len[k] < 1 || agent->grid_len[k] > FRIRL_HIP_MAX_GRID) { set_error("frirl_hip_rollout_shared: grid_len[%d]=%d outside 1..%d", k, agent->grid_len[k], FRIRL_HIP_MAX_GRID); return FRIRL_HIP_EINVAL; }
     if ((ro->exclude_mask == nullptr) != (ro->rule_slot == nullptr)) { set_error("frirl_hip_rollout_shared: exclude_mask and rule_slot go together"); return FRIRL_HIP_EINVAL; }

@@ -176,7 +176,7 @@ typedef struct frirl_hip_agent {
 
 /* frirl_test_run's greedy roll-out (reference src/frirl/frirl_test_run.c:66-70 -> frirl_episode with reduction_state == 1,
  * frirl_episode.c:28-194 without the update at :155) for Q environments sharing ONE read-only rule base: lane =
- * environment, whole episodes in one launch (default Shepard power only: agent->p <= 0 or == nant).  `agent` as for the episode entry points (env_kind, max_steps, grids, action
+ * environment, whole episodes in one launch (a Shepard power agent->p != nant runs the variants without rule slices).  `agent` as for the episode entry points (env_kind, max_steps, grids, action
  * values / VE points, epsilon-greedy stream keyed by env_id_base + row; alpha/gamma/... unused).
  * Optional "try-remove" view of the rule base (the replays of the rule-base reduction, frirl_sequential_run.c:170-350):
  * rule r carries a candidate slot rule_slot[r] (0..31, 255 = not a candidate); environment q ignores every rule whose
@@ -231,6 +231,12 @@ typedef struct frirl_hip_envs {
     const double *start_states; /* [dev] [E][nant-1] per-environment episode start state, or NULL = agent->values_def
                                    (reference: gen_def_states randomises it per agent, frirl_agent.c:121-139) */
     int32_t *episode;        /* [dev] [E] episodes started so far (RNG stream position), or NULL          */
+    double *spread_ant;      /* [dev] [E][nant] antecedents of the last INTERPOLATED update_rules call, or NULL   */
+    int32_t *spread_R;       /* [dev] [E] rule count at that call (0 = none since the last frirl_hip_weights_from_spread), or NULL.
+                                Together they determine FIVERB.weights as the reference leaves it after learning (the array is
+                                only rewritten when FIVE_vag_concl_weight interpolates, frirl_update_sarsa.c:40, FIVEVagConclWeight.c:67-69;
+                                antecedents of existing rules never change), without the learning kernels materialising it:
+                                frirl_hip_weights_from_spread rebuilds it where the rule-base merge needs it */
 } frirl_hip_envs;
 
 /* Per-environment convergence state of the construct loop (reference frirl_sequential_run.c:55-165). */
@@ -304,8 +310,8 @@ int frirl_hip_episode_steps(const frirl_hip_tables *t, const frirl_hip_rulebases
  * per launch (same contract as frirl_hip_episode_steps: finished environments sit out, status[e] = update of the last step).  The rule bases are transposed into
  * `workspace` ([dev], >= frirl_hip_lanes_workspace_bytes) on entry and back on exit.  Decisions (actions, hits,
  * inserted rules) and distances are those of the step kernel; interpolated Q agrees to ~1e-15 (different summation
- * order than the tree of the per-environment kernels, same as the reference's).  Built for the default Shepard power
- * (agent->p <= 0 or == nant, FIVEInit.c:89-93); any other p is FRIRL_HIP_EINVAL -- use frirl_hip_episode_steps. */
+ * order than the tree of the per-environment kernels, same as the reference's).  The default Shepard power (agent->p <= 0 or == nant,
+ * FIVEInit.c:89-93) is a compile-time constant of the kernels; any other p runs the run-time-power variants (no rule slices). */
 size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
 /* 1 when the lane-group form is expected to beat the per-environment kernels for this batch shape: with up to 8 rule
  * slices it did at every size measured (96 ... 65 536 agents of the three demos), so this is 1 for every valid shape */
@@ -460,6 +466,10 @@ int frirl_hip_batch_train_merged(frirl_hip_batch *b, int32_t max_episodes, int32
  * The sender rules are read as rant[r * rule_stride + k * dim_stride] (AoS like FIVERB.rant: rule_stride = nant, dim_stride = 1;
  * a row set of frirl_hip_envs.rant: rule_stride = 1, dim_stride = maxR) and rconc[r]; S_dev != NULL: the count is read on the
  * device (e.g. &nrules[sender]).  The sender must not be one of the active receivers.  full[e] = 1 when an append was refused. */
+/* FIVERB.weights of every rule base as the reference's learning loop left it: for environments with envs->spread_R[e] > 0 the
+ * normalised Shepard weights of envs->spread_ant[e] over the first spread_R[e] rules are written to weights[e][0 .. spread_R[e]) and
+ * spread_R[e] is reset to 0; other rows are left as they are (e.g. what the previous merge left). */
+int frirl_hip_weights_from_spread(const frirl_hip_tables *t, const frirl_hip_rulebases *b, int p, const frirl_hip_envs *envs, double *weights, void *stream);
 typedef struct frirl_hip_sender {
     const double *rant;         /* [dev] */
     int64_t rule_stride, dim_stride;

@@ -6,8 +6,10 @@ contract (asserted at 1e-9: the merge multiplies interpolated values, never comp
 The receiver's weights array: merge_rb re-uses FIVERB.weights across sender rules, and an exact-hit sender rule leaves it
 untouched (FIVEVagConclWeight.c:67-69) -- so at the START of a merge the reference still holds the weights of the agent's last
 interpolated SARSA update.  The C ABI makes that array an explicit caller-owned buffer: given the reference's array state
-(taken here from the oracle agent that reproduces the golden `agent_before`) the GPU reproduces the genuine `agent_after`;
-the library's own loop (frirl_hip_batch_merge_round) starts from zeros / what its previous merge left (deviations)."""
+(taken here from the oracle agent that reproduces the golden `agent_before`) the GPU reproduces the genuine `agent_after`.
+The library's own loop (frirl_hip_batch_merge_round) rebuilds that state with frirl_hip_weights_from_spread from the antecedents
+and rule count of each agent's last interpolated update, which the learning kernels record (frirl_hip_envs.spread_*): the C-level
+merged training below follows the oracle loop with NO adjustment of the oracle's weights arrays."""
 import json
 import os
 
@@ -185,8 +187,6 @@ def test_c_level_merged_training_follows_the_oracle(env, agents, tmp_path):
     assert not done[0]
     m = ag[0].five
     mr, mc = np.array(m.rant[: m.R]), np.array(m.rconc[: m.R])
-    for a in ag:
-        a.five.weights[:] = 0.0       # the library's merge starts from a zeroed weights array (module docstring)
     for i in range(1, agents):
         ag[i].five.merge_rb(ag[i].agent(), mr, mc)
     for i in range(1, agents):

@@ -180,17 +180,17 @@ def test_persistent_episode_kernel_keeps_the_index_mirror_in_sync(env):
     assert (h_idx == h_f64).all() and (d_idx[:, :R].view(torch.int64) == d_f64[:, :R].view(torch.int64)).all()
 
 
-def test_non_default_shepard_power_takes_the_per_environment_kernels():
-    """A Shepard power p != nant (the reference accepts any p, FIVEInit.c:89-93) is served by the per-environment kernels: train()
-    must not pick the lane-group kernel, and the LDS-persistent episode kernel (with its hand-off to the step kernel when the slab
-    fills: status FULL) must give exactly the bits of the plain step kernel."""
+def test_non_default_shepard_power():
+    """A Shepard power p != nant (the reference accepts any p, FIVEInit.c:89-93): the LDS-persistent episode kernel (with its hand-off
+    to the step kernel when the slab fills: status FULL) must give exactly the bits of the plain step kernel, and the lane-group
+    kernel's run-time-power variants must learn the same rule bases."""
     import torch
     dev = torch.device("cuda", 0)
 
     def run(persistent):
         prob, agent, envs = frirl_amd.demo_fresh_batch("acrobot", 5, 1024, dev, p=2)
         assert agent.desc.p == 2
-        conv = frirl_amd.train(prob, agent, envs, max_episodes=40, persistent=persistent, persistent_max_rules=1024)
+        conv = frirl_amd.train(prob, agent, envs, max_episodes=40, persistent=persistent, persistent_max_rules=1024, lanes=False)
         torch.cuda.synchronize()
         return prob, envs, conv
 
@@ -199,8 +199,42 @@ def test_non_default_shepard_power_takes_the_per_environment_kernels():
     assert (pa.rb == pb.rb).all() and (pa.nrules == pb.nrules).all() and (pa.uidx == pb.uidx).all()
     assert (ea.rant == eb.rant).all() and (ca.episodes == cb.episodes).all()
     assert int(pa.nrules.max()) > 64, "the rule bases grew"
-    # and the lane-group entry point refuses the power instead of computing with the wrong one
-    with pytest.raises(frirl_amd.FrirlHipError):
-        prob, agent, envs = frirl_amd.demo_fresh_batch("acrobot", 5, 1024, dev, p=2)
-        frirl_amd.episode_begin(prob, agent, envs)
-        frirl_amd.episode_run_lanes(prob, agent, envs, 10)
+    # the lane-group kernel (run-time power variants) learns the same rule bases: decisions exact, Q to rounding
+    pl, agent_l, el = frirl_amd.demo_fresh_batch("acrobot", 5, 1024, dev, p=2)
+    cl = frirl_amd.train(pl, agent_l, el, max_episodes=40, lanes=True)
+    torch.cuda.synchronize()
+    assert (pl.nrules == pb.nrules).all() and (cl.episodes == cb.episodes).all()
+    assert (el.rant == eb.rant).all() and (pl.rb[:, : pl.nant] == pb.rb[:, : pb.nant]).all()
+    qa, qb = pl.rb[:, pl.nant], pb.rb[:, pb.nant]
+    assert ((qa - qb).abs() <= 1e-9 * qb.abs().clamp_min(1e-9)).all()
+    # ... and differs from the default power (the option is really used)
+    pd, agent_d, ed = frirl_amd.demo_fresh_batch("acrobot", 5, 1024, dev)
+    frirl_amd.train(pd, agent_d, ed, max_episodes=40, lanes=True)
+    torch.cuda.synchronize()
+    assert not (pd.rb[:, pd.nant] == qa).all()
+
+
+def test_rollout_on_shared_rule_base_with_non_default_power():
+    """frirl_hip_rollout_shared with p != nant (run-time power variants) == the per-environment step kernels in evaluate mode."""
+    import torch
+    dev = torch.device("cuda", 0)
+    prob, agent, envs = frirl_amd.demo_fresh_batch("mountaincar", 1, 512, dev, p=2)
+    frirl_amd.train(prob, agent, envs, max_episodes=12, lanes=False)
+    Q = 300
+    d = frirl_amd.demo_describe("mountaincar")
+    g = torch.Generator(device=dev).manual_seed(3)
+    lo = torch.tensor([d["grids"][k].min() for k in range(2)], dtype=torch.float64, device=dev)
+    hi = torch.tensor([d["grids"][k].max() for k in range(2)], dtype=torch.float64, device=dev)
+    ss = (lo + (hi - lo) * torch.rand((Q, 2), dtype=torch.float64, device=dev, generator=g)).contiguous()
+    one = frirl_amd.Problem(prob.u, prob.ve, prob.rb[0:1].clone(), prob.nrules[0:1].clone())
+    steps, reward, _, _ = one.rollout_shared(agent, Q, start_states=ss)
+    # reference: Q copies of the rule base, evaluate-mode episodes through the step kernel
+    many = frirl_amd.Problem(prob.u, prob.ve, prob.rb[0:1].expand(Q, -1, -1).contiguous(), prob.nrules[0:1].expand(Q).contiguous())
+    ev_agent = frirl_amd.demo_agent(d, dev, p=2, evaluate=1)
+    envs2 = frirl_amd.Envs(many, dev, keep_rant=False, start_states=ss)
+    frirl_amd.episode_begin(many, ev_agent, envs2)
+    frirl_amd.episode_steps(many, ev_agent, envs2, ev_agent.desc.max_steps)
+    torch.cuda.synchronize()
+    same = (steps == envs2.ep_steps)
+    assert same.float().mean() > 0.98, same.float().mean()        # sequential vs tree sums: a near-tie may flip an action
+    assert ((reward - envs2.ep_reward).abs()[same] <= 1e-9 * envs2.ep_reward.abs()[same].clamp_min(1.0)).all()
