@@ -12,7 +12,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-HIP_LIB_PATH = os.path.join(PKG_DIR, "lib", "libfrirl_hip.so")
+HIP_LIB_PATH = os.environ.get("FRIRL_HIP_LIB_OVERRIDE") or os.path.join(PKG_DIR, "lib", "libfrirl_hip.so")      # override: A/B of experimental builds (tools/)
 
 NO_HIT = 0xFFFFFFFF
 MAX_NANT = 16

@@ -250,7 +250,10 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 // for the others -- without the bound the 5-antecedent, many-action variants sit just above 128 and lose a wave
 // (the action-parallel kernel, amax > 8: 3 waves = 168 VGPRs -- its branch-free conclusion terms keep more chains in flight, and with
 // cartpole's 40 KB of LDS tables only three workgroups fit a CU anyway)
-constexpr int step_min_waves(int nant, int amax) { return (nant <= 3 && amax <= 4) ? 6 : (amax > 8 ? 3 : 4); }
+#ifndef FRIRL_STEP_WAVES_N3
+#define FRIRL_STEP_WAVES_N3 6
+#endif
+constexpr int step_min_waves(int nant, int amax) { return (nant <= 3 && amax <= 4) ? FRIRL_STEP_WAVES_N3 : (amax > 8 ? 3 : 4); }
 
 // TRACK: the candidates of update_rules' write-back are collected during the fused sweep (sweeps.h: SpreadCand) -- for LARGE rule
 // bases, where the second sweep it saves is a second pass over HBM; small slabs are re-read from L2 and the plain form is faster.

@@ -396,7 +396,8 @@ int five_hip_mirror_greedy_step(five_hip_mirror *m, const frirl_hip_agent *agent
 /* =================================================================================================
  * Batch object, HOST descriptors: E agents of one problem owned by the library (device memory, stream,
  * convergence state).  The C-level counterpart of the reference's many-agent run modes
- * (frirl_omp_run / frirl_mpi_run, src/frirl/frirl_agent.c:294-467) without the rule-base merge: every
+ * (frirl_omp_run / frirl_mpi_run, src/frirl/frirl_agent.c:294-467); frirl_hip_batch_train learns without the rule-base exchange,
+ * frirl_hip_batch_train_merged / _merge_round (below) with it: every
  * agent owns its rule base and learns independently; only statistics leave the device.  The environment
  * must be one of the built-in kinds (agent.env_kind), because its step() runs on the device.
  * ================================================================================================= */
@@ -486,7 +487,7 @@ int frirl_hip_gen_def_states(const double *master_rant, int32_t R, int32_t nant,
 
 /* =================================================================================================
  * Many agents over several GPUs of one node, from plain C (the reference's frirl_omp_run / frirl_mpi_run shape,
- * src/frirl/frirl_agent.c:294-467, without the rule-base merge): `total_agents` agents are sharded over `ngpus` visible
+ * src/frirl/frirl_agent.c:294-467; the rule-base exchange stays inside one device's batch): `total_agents` agents are sharded over `ngpus` visible
  * devices by GLOBAL environment id (frirl_hip_shard: balanced contiguous partition; RNG streams and start states are keyed by
  * the global id, so trajectories do not depend on the sharding), one frirl_hip_batch and one host thread per device, no
  * data-path collective.  The only exchange is the per-episode report (sums of reward / steps / rules / converged, reward
