@@ -335,7 +335,8 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
 // are written back with the rest of the slab when the wave leaves (episode end, nsteps exhausted, or the LDS slab
 // full: then status = FRIRL_HIP_UPD_FULL with done == 0 and the caller continues with the step kernel).
 // Arithmetic, lane mapping and reduction order are those of the one-wave step kernel => bit-identical results.
-template <int NANT, int AMAX, int CAP>
+// PN: Shepard power = nant as a compile-time constant, exactly as in the step kernel (the two forms of the weight differ in their last bits).
+template <int NANT, int AMAX, int CAP, bool PN>
 __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                                   double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules, int maxR,
                                                                   const frirl_hip_agent ag, const frirl_hip_envs ev, int nsteps)
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
     uint16_t *uidx_e = uidx ? uidx + (size_t)e * NANT * maxR : nullptr;      // 16-bit index mirror: appends are written through (five_add_rule.c:76)
     const ColsLds cols{slab_s, CAP};
     double *qcol = slab_s + (size_t)NANT * CAP;
-    const int p = ag.p > 0 ? ag.p : NANT;
+    const auto p = PowSel<PN, NANT>::make(ag.p > 0 ? ag.p : NANT);
     __syncthreads();
 
     for (int it = 0; it < nsteps; it++) {
@@ -788,12 +789,15 @@ static void launch_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
                        int lds_rules, hipStream_t s)
 {
     const size_t dyn = 2 * sizeof(double) * t->nant * (size_t)t->U;
-#define RUN(CAP_) hipLaunchKernelGGL((frirl::episode_run_kernel<N, AMAX, CAP_>), dim3(b->E), dim3(FRIRL_WAVE), dyn, s, t->u, t->ve, t->U, b->rb, b->uidx, b->nrules, \
-                                     b->maxR, *ag, *ev, nsteps)
+    const bool pn = ag->p <= 0 || ag->p == N;
+#define RUN1(CAP_, PN_) hipLaunchKernelGGL((frirl::episode_run_kernel<N, AMAX, CAP_, PN_>), dim3(b->E), dim3(FRIRL_WAVE), dyn, s, t->u, t->ve, t->U, b->rb, b->uidx, \
+                                           b->nrules, b->maxR, *ag, *ev, nsteps)
+#define RUN(CAP_) do { if (pn) RUN1(CAP_, true); else RUN1(CAP_, false); } while (0)
     if (lds_rules <= 256) RUN(256);
     else if (lds_rules <= 512) RUN(512);
     else RUN(1024);
 #undef RUN
+#undef RUN1
 }
 
 extern "C" int frirl_hip_episode_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,

@@ -10,6 +10,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "device_common.h"
 
 namespace frirl {
@@ -65,19 +67,85 @@ struct PowC {};
 
 __device__ __forceinline__ double shepard_w(double s, int p) { return inv_dist_pow<false>(s, p); }
 
+// Straight-line form for a compile-time power (the hot kernels).  Instead of refining y = s^(-1/2) and THEN raising it to P, the
+// power of the raw v_rsq_f64 value y0 (relative error <= 5.2e-8) is corrected once: with e = 1 - s y0^2,
+//   s^(-P/2) = y0^P (1 - e)^(-P/2) = y0^P (1 + a e + a (a + 1) / 2 e^2 + O(e^3)),  a = P / 2,  |O(e^3)| < 1e-20,
+// and y0^2 is shared between e and the power: 7 FP64 instructions after the rsq for P = 5 (y2, e, y4, y5, c, c e, fma) instead of
+// 9 (6 instead of 7 for P = 3), same 1e-16 accuracy (tools/exp/shepard_prec.hip).  v_rsq_f64 itself issues in ~3.4 FP64 slots
+// (tools/exp/valu_cost.hip); the f32 detour (cvt, v_rsq_f32, cvt) costs the same.
+#ifndef FRIRL_SHEPARD_SERIES
+#define FRIRL_SHEPARD_SERIES 1
+#endif
+template <int P>
+__device__ __forceinline__ double shepard_series(double s, double a, double a2)
+{
+    const double y = __builtin_amdgcn_rsq(s);
+    const double y2 = y * y;
+    const double e = __fma_rn(-s, y2, 1.0);
+    double yp;
+    if constexpr (P == 1) yp = y;
+    else if constexpr (P == 2) yp = y2;
+    else if constexpr (P == 3) yp = y2 * y;
+    else if constexpr (P == 4) yp = y2 * y2;
+    else if constexpr (P == 5) { const double y4 = y2 * y2; yp = y4 * y; }
+    else if constexpr (P == 6) { const double y4 = y2 * y2; yp = y4 * y2; }
+    else if constexpr (P == 8) { const double y4 = y2 * y2; yp = y4 * y4; }
+    else {
+        yp = y2;
+#pragma unroll
+        for (int i = 2; i < P; i++) yp = yp * y;
+    }
+    const double c = __fma_rn(a2, e, a);
+    const double ce = c * e;
+    return __fma_rn(yp, ce, yp);
+}
+
 template <int P>
 __device__ __forceinline__ double shepard_w(double s, PowC<P>)
 {
-    double y = __builtin_amdgcn_rsq(s);
+#if FRIRL_SHEPARD_SERIES
+    constexpr double a = 0.5 * P, a2 = 0.5 * a * (a + 1.0);
+    return shepard_series<P>(s, a, a2);
+#else
+    const double y = __builtin_amdgcn_rsq(s);
     const double t = s * y;
     const double e = __fma_rn(-t, y, 1.0);
     const double c = __fma_rn(0.375, e, 0.5);
     const double ce = c * e;
-    y = __fma_rn(y, ce, y);
-    double w = y;
+    const double yr = __fma_rn(y, ce, y);
+    double w = yr;
 #pragma unroll
-    for (int i = 1; i < P; i++) w = w * y;       // same multiplication order as the run-time loop: bit-identical results
+    for (int i = 1; i < P; i++) w = w * yr;
     return w;
+#endif
+}
+
+// The same with the two series coefficients held in registers for the whole sweep (a: VGPR pair, a2: SGPR pair -- a VOP3 takes one
+// scalar operand): as immediates the compiler rebuilds `a` with two v_mov_b32 in front of every v_fmac (neither is an inline
+// constant), ~1 FP64 issue slot per conclusion.  For the FP64-issue-bound action-parallel sweep, which has the registers.
+template <int P>
+struct PowCP { double a, a2; };
+template <int P>
+__device__ __forceinline__ PowCP<P> pin_pow(PowC<P>)
+{
+    PowCP<P> r;
+    r.a = 0.5 * P;
+    r.a2 = 0.5 * (0.5 * P) * (0.5 * P + 1.0);
+#if FRIRL_SHEPARD_SERIES
+    asm volatile("" : "+v"(r.a));
+    asm volatile("" : "+s"(r.a2));
+#endif
+    return r;
+}
+__device__ __forceinline__ int pin_pow(int p) { return p; }
+template <int P>
+__device__ __forceinline__ double shepard_w(double s, PowCP<P> k)
+{
+#if FRIRL_SHEPARD_SERIES
+    return shepard_series<P>(s, k.a, k.a2);
+#else
+    return shepard_w(s, PowC<P>());
+#endif
 }
 
 // run-time power with the p = 3 / 5 cases unrolled (low-occupancy kernels)
@@ -413,6 +481,32 @@ struct GbaScratch {
     int best;
 };
 
+// One action against a PAIR of rules whose state parts s0, s1 are both non-zero: no exact hit is possible (d^2 >= s > 0), so the
+// conclusion terms need neither compares nor branches.  The action-parallel sweep takes this path whenever no lane of the wave holds
+// a rule with a zero state part or an odd tail (wave-uniform test, once per pair of rules instead of twice per action): per conclusion
+// it removes a v_cmp and the ~6 scalar / exec-mask instructions of the two branches (cartpole's 21-action step: 1.05e9 vector + 3.6e8
+// scalar wave-instructions per step before; 2.54 -> 2.41 ms per 4096 environments).  Same operations in the same order as the general
+// form => bit-identical sums.  Not used in sweep_gba / sweep_gba_q: their kernels run at the 80 / 128-VGPR budgets and the second
+// loop body spills the hot loop (mountaincar step 0.25 -> 0.75 ms), and the 5-antecedent / 3-action step is HBM-bound anyway.
+#ifndef FRIRL_GBA_FASTPATH
+#define FRIRL_GBA_FASTPATH 1
+#endif
+template <class POW>
+__device__ __forceinline__ void concl_pair_nohit(double av, const double2 &va, double s0, double s1, const double2 &c, POW p, double &sv, double &sw)
+{
+    const double e0 = av - va.x, e1 = av - va.y;
+    const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);
+    const double w0 = shepard_w(d0, p), w1 = shepard_w(d1, p);
+    sv = __fma_rn(w0, c.x, sv);
+    sw = sw + w0;
+    sv = __fma_rn(w1, c.y, sv);
+    sw = sw + w1;
+}
+__device__ __forceinline__ bool wave_no_state_hit(bool second, double s0, double s1)
+{
+    return FRIRL_GBA_FASTPATH && __builtin_amdgcn_ballot_w64(!second || s0 == 0.0 || s1 == 0.0) == 0ull;
+}
+
 template <int NANT, int AMAX, int BLOCK, class COLS, class POW>
 __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1], POW p, int A,
                          GbaScratch<AMAX, BLOCK> &s)
@@ -631,11 +725,15 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
     constexpr int WAVES = BLOCK / FRIRL_WAVE;
     if (TRACK) slot[threadIdx.x].clear();          // `slot` = the workgroup's slot array, one entry per lane
     track_thr = wave_uniform(track_thr * SPREAD_PREFILTER_SLACK);
-    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
-    const int ag = (A + WAVES - 1) / WAVES;            // actions per wave (<= AG)
-    const int a_begin = wave * ag;
-    int na = A - a_begin;                              // actions of this wave
-    na = na < 0 ? 0 : (na > ag ? ag : na);
+    // `wave` as a scalar: the compiler cannot see that threadIdx.x / 64 is wave-uniform and would mask every per-wave decision with exec
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FRIRL_WAVE));
+    // actions per wave: as even as A allows (21 over 4 waves: 6 + 5 + 5 + 5, not 6 + 6 + 6 + 3).  Every action is summed by ONE wave over
+    // all rules in rule order, so results do not depend on the assignment.  (Rotating the wave that carries the extra action with a
+    // hash of blockIdx -- the waves of a workgroup land on the four SIMDs in launch order -- measured no difference: 2.41 vs 2.42 ms.)
+    const int vw = wave;
+    const int a_lo = A / WAVES, a_rem = A % WAVES;
+    const int a_begin = vw * a_lo + (vw < a_rem ? vw : a_rem);
+    const int na = a_lo + (vw < a_rem ? 1 : 0);        // actions of this wave (<= AG)
     double sv[AG], sw[AG], av[AG];
     unsigned sh[AG];
 #pragma unroll
@@ -653,6 +751,13 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
     }
     double T = 0.0;
     const int r_lim = (WITH_Q && TRACK) ? wave_uniform_limit(R) : R;      // see sweep_gba_q
+    // The rule loop, specialised for the number of actions NA of this wave (a generic lambda instantiated for 0..AG and selected once
+    // per wave): with the run-time bound `j < na` inside the loop every action sits behind its own exec-mask test, which also keeps the
+    // scheduler from interleaving the FP64 chains of different actions.  Waves of one workgroup may run different instances; they meet
+    // at the same barriers (same trip count).
+    const auto pk = pin_pow(p);
+    auto rule_loop = [&](auto na_c) {
+    constexpr int NA = decltype(na_c)::value;
     for (int r = 2 * lane; r < r_lim; r += 2 * FRIRL_WAVE, it++) {
         // the waves read the same lines: a barrier every few iterations keeps them within the window the vector L1 still holds
         // (trip count and `it` are the same for every wave of the workgroup)
@@ -705,20 +810,36 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                 }
             }
             const double2 va = v[NS];
+            if (wave_no_state_hit(second, s0, s1)) {
 #pragma unroll
-            for (int j = 0; j < AG; j++) {
-                if (j < na) {
+                for (int j = 0; j < NA; j++) concl_pair_nohit(av[j], va, s0, s1, c, pk, sv[j], sw[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NA; j++) {
                     const double e0 = av[j] - va.x, e1 = av[j] - va.y;
                     const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);
                     if (d0 == 0.0) sh[j] = min(sh[j], (unsigned)r);
-                    else { const double wi = shepard_w(d0, p); sv[j] = __fma_rn(wi, c.x, sv[j]); sw[j] = sw[j] + wi; }
+                    else { const double wi = shepard_w(d0, pk); sv[j] = __fma_rn(wi, c.x, sv[j]); sw[j] = sw[j] + wi; }
                     if (second) {
                         if (d1 == 0.0) sh[j] = min(sh[j], (unsigned)(r + 1));
-                        else { const double wi = shepard_w(d1, p); sv[j] = __fma_rn(wi, c.y, sv[j]); sw[j] = sw[j] + wi; }
+                        else { const double wi = shepard_w(d1, pk); sv[j] = __fma_rn(wi, c.y, sv[j]); sw[j] = sw[j] + wi; }
                     }
                 }
             }
         }
+    }
+    };
+    static_assert(AG == 8, "the dispatch below enumerates 0..8 actions per wave");
+    switch (na) {
+        case 0: rule_loop(std::integral_constant<int, 0>()); break;
+        case 1: rule_loop(std::integral_constant<int, 1>()); break;
+        case 2: rule_loop(std::integral_constant<int, 2>()); break;
+        case 3: rule_loop(std::integral_constant<int, 3>()); break;
+        case 4: rule_loop(std::integral_constant<int, 4>()); break;
+        case 5: rule_loop(std::integral_constant<int, 5>()); break;
+        case 6: rule_loop(std::integral_constant<int, 6>()); break;
+        case 7: rule_loop(std::integral_constant<int, 7>()); break;
+        default: rule_loop(std::integral_constant<int, 8>()); break;
     }
 #pragma unroll
     for (int j = 0; j < AG; j++) {
