@@ -113,6 +113,7 @@ struct Options {
     int lanes_wpe;        // lane groups: waves per SIMD, 0 = by shape                           (FRIRL_HIP_LANES_WPE)
     int rollout_group;    // shared-base roll-out: lanes per environment, 0 = by shape           (FRIRL_HIP_ROLLOUT_GROUP)
     int rollout_slices;   // shared-base roll-out: rule slices, 0 = by shape                     (FRIRL_HIP_ROLLOUT_SLICES)
+    int no_many;          // 9..24 actions: 1 = action-parallel waves (sweep_gba_wide) instead of all actions in registers (FRIRL_HIP_NO_MANY)
 };
 const Options &opts();
 }  // namespace frirl_host

@@ -86,7 +86,11 @@ __global__ __launch_bounds__(BLOCK) void get_best_action_kernel(const double *__
     const double *qcol = base + (size_t)NANT * maxR;
     const auto cols = ColsSel<IDX>::make(base, uidx + (IDX ? (size_t)e * NANT * maxR : 0), tab_s, maxR, U);
     int b;
-    if (AMAX > 8) {
+    if constexpr (AMAX == 24) {                 // 9..24 actions, 256 threads: every action in registers (sweep_gba_many)
+        __shared__ BlockRed<BLOCK> red;
+        double dummy[NANT] = {};
+        b = sweep_gba_many<NANT, AMAX, BLOCK, false>(cols, qcol, R, q, dummy, p, A, gs, red, nullptr);
+    } else if constexpr (AMAX > 8) {
         __shared__ BlockRed<BLOCK> red;
         double dummy[NANT] = {};
         b = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(cols, qcol, R, q, dummy, p, A, gs, red, nullptr);
@@ -184,7 +188,12 @@ static void launch_gba(const frirl_hip_tables *t, const frirl_hip_rulebases *b, 
     } while (0)
     if (A <= 4) L(4);
     else if (A <= 8) L(8);
-    else L(32);            // > 8 actions: action-parallel waves (sweep_gba_wide)
+    else if (A <= 24 && !big && !frirl_host::opts().no_many) {      // 9..24 actions: every action in registers (sweep_gba_many; 256 threads)
+        if (idx) hipLaunchKernelGGL((frirl::get_best_action_kernel<N, 24, 256, true>), dim3(b->E), dim3(256), tab, s, t->u, t->ve, t->U, b->rb,
+                                    b->uidx, b->nrules, b->maxR, p, states, action_ve, A, actconc, best);
+        else hipLaunchKernelGGL((frirl::get_best_action_kernel<N, 24, 256, false>), dim3(b->E), dim3(256), 0, s, t->u, t->ve, t->U, b->rb,
+                                b->uidx, b->nrules, b->maxR, p, states, action_ve, A, actconc, best);
+    } else L(32);          // more actions, or few environments: action-parallel waves (sweep_gba_wide)
 #undef L
 }
 

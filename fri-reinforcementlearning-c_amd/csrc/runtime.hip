@@ -36,6 +36,7 @@ static const OptName k_opts[] = {
     {"lanes_wpe", "FRIRL_HIP_LANES_WPE", &Options::lanes_wpe, 0},
     {"rollout_group", "FRIRL_HIP_ROLLOUT_GROUP", &Options::rollout_group, 0},
     {"rollout_slices", "FRIRL_HIP_ROLLOUT_SLICES", &Options::rollout_slices, 0},
+    {"no_many", "FRIRL_HIP_NO_MANY", &Options::no_many, 0},
 };
 static void opts_init()
 {

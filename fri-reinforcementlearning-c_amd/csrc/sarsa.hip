@@ -226,7 +226,11 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
     const auto cols = ColsSel<IDX>::make(base, uidx + (IDX ? (size_t)e * NANT * maxR : 0), tab_s, maxR, U);
     const auto pw = PowSel<PN, NANT>::make(ag.p > 0 ? ag.p : NANT);
     int a0;
-    if (AMAX > 8) {
+    if constexpr (AMAX == 24) {
+        __shared__ BlockRed<BLOCK> red;
+        double dummy[NANT] = {};
+        a0 = sweep_gba_many<NANT, AMAX, BLOCK, false>(cols, qcol, nrules[e], q, dummy, pw, ag.A, gs, red, nullptr);   // :78
+    } else if constexpr (AMAX > 8) {
         __shared__ BlockRed<BLOCK> red;
         double dummy[NANT] = {};
         a0 = sweep_gba_wide<NANT, 8, AMAX, BLOCK, false>(cols, qcol, nrules[e], q, dummy, pw, ag.A, gs, red, nullptr);   // :78
@@ -301,8 +305,10 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     const auto pw = PowSel<PN, NANT>::make(ag.p > 0 ? ag.p : NANT);
     QResult rn;
     // one pass over the slab: greedy action for s' (:148) AND Q(s,a) of the pending update (frirl_update_sarsa.c:357)
-    const int ap = (AMAX > 8) ? sweep_gba_wide<NANT, 8, AMAX, BLOCK, true, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn, ag.weight_significant, cand_s)
-                              : sweep_gba_q<NANT, AMAX, BLOCK, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
+    int ap;
+    if constexpr (AMAX == 24) ap = sweep_gba_many<NANT, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn);
+    else if constexpr (AMAX > 8) ap = sweep_gba_wide<NANT, 8, AMAX, BLOCK, true, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn, ag.weight_significant, cand_s);
+    else ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
     if (threadIdx.x == 0) {
         const int chosen = e_greedy(ag, ap, (uint32_t)e, ev.episode ? (uint32_t)ev.episode[e] : 0u, (uint32_t)ev.ep_steps[e] + 1u);
         gs.best = chosen;
@@ -676,7 +682,8 @@ static void launch_episode(const frirl_hip_tables *t, const frirl_hip_rulebases 
     if (sw >= 0) small = sw == 1;
     if (ag->A <= 4) { if (small) launch_episode_v<N, 4, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 4, 256, BEGIN>(t, b, ag, ev, s); }
     else if (ag->A <= 8) { if (small) launch_episode_v<N, 8, 64, BEGIN>(t, b, ag, ev, s); else launch_episode_v<N, 8, 256, BEGIN>(t, b, ag, ev, s); }
-    else launch_episode_v<N, 32, 256, BEGIN>(t, b, ag, ev, s);            // > 8 actions: action-parallel waves (sweep_gba_wide)
+    else if (ag->A <= 24 && !frirl_host::opts().no_many) launch_episode_v<N, 24, 256, BEGIN>(t, b, ag, ev, s);   // 9..24 actions: all in registers (sweep_gba_many)
+    else launch_episode_v<N, 32, 256, BEGIN>(t, b, ag, ev, s);            // more: action-parallel waves (sweep_gba_wide)
 }
 
 // 1 when frirl_hip_episode_step streams the 16-bit index mirror for this shape (given that the caller provides one)

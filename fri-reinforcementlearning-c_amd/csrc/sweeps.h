@@ -476,6 +476,7 @@ struct GbaScratch {
     double v[WAVES][AMAX];
     double w[WAVES][AMAX];
     unsigned h[WAVES][AMAX];
+    unsigned hit[AMAX];         // sweep_gba_many: first exact hit per action (atomic min)
     double actconc[AMAX];
     double ave[AMAX];
     int best;
@@ -693,6 +694,132 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     if (threadIdx.x == 0) {
         int best = 0;
         for (int a = 1; a < A; a++) if (s.actconc[best] < s.actconc[a]) best = a;
+        s.best = best;
+    }
+    __syncthreads();
+    return s.best;
+}
+
+// Many-action greedy sweep with EVERY action in registers (9 <= A <= AMAX = 24; cartpole: 21).  The action-parallel form below
+// (sweep_gba_wide) repeats the decode and the state part of every rule pair in each of its four waves (~18 % of its issue slots) and
+// relies on the vector L1 to absorb the fourfold column reads.  Here the waves take different rule pairs, as in sweep_gba_q, and one lane
+// keeps all A accumulator pairs: 4 A VGPRs (84 at A = 21) -- affordable because nothing else per action lives in vector registers:
+//  * the action VE values sit in SGPRs (wave-uniform; a VOP3 reads one scalar operand);
+//  * exact hits never touch the sums: an action that has an exact hit anywhere takes its conclusion from that rule and its Shepard sums
+//    are discarded (FIVEVagConcl_FRIRL_BestAct.c:89-93), so the hot loop lets 1/0 poison the sums of exactly that action and only
+//    RECORDS the hit -- in a rare side path (some lane's rule has a zero state part) that scans the actions for av[a] == va and
+//    takes an LDS atomic min.  One loop body, no per-action compare, branch or select;
+//  * the odd tail (r + 1 == R) gets a huge state part: its weight underflows to exactly 0, adding +0 to both sums.
+// Actions are unrolled in groups of three behind one scalar test per group (A is rounded up to a multiple of three with copies of the
+// last action, whose sums nobody reads): six independent FP64 chains per group.  Per-lane sums are in rule order, the combine is the
+// fixed butterfly + wave order of sweep_gba.  WITH_Q adds the Q(s,a) sums of the fused step with sweep_q's lane mapping.
+template <int NANT, int AMAX, int BLOCK, bool WITH_Q, class COLS, class POW>
+__device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
+                              const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult *qres)
+{
+    constexpr int NS = NANT - 1;
+    constexpr int G = 3;
+    static_assert(AMAX % G == 0, "groups of three actions");
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FRIRL_WAVE));
+    double sv[AMAX], sw[AMAX], av[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; av[a] = wave_uniform(s.ave[a < A ? a : A - 1]); }
+    if ((int)threadIdx.x < AMAX) s.hit[threadIdx.x] = FRIRL_HIP_NO_HIT;
+    __syncthreads();
+    unsigned qbest = FRIRL_HIP_NO_HIT;
+    double qv = 0.0, qw = 0.0;
+    const auto pk = pin_pow(p);
+    typename COLS::raw_t nraw[NANT];
+    double2 nc = {0.0, 0.0};
+    {
+        const int r0 = 2 * (int)threadIdx.x;
+        if (r0 < R) {
+#pragma unroll
+            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r0);
+            nc = load_col2(qcol + r0);
+        }
+    }
+    for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
+        const bool second = (r + 1 < R);
+        double2 v[NANT];
+        typename COLS::raw_t raw[NANT];
+#pragma unroll
+        for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
+        const double2 c = nc;
+        if (r + 2 * BLOCK < R) {
+#pragma unroll
+            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * BLOCK);
+            nc = load_col2(qcol + r + 2 * BLOCK);
+        }
+#pragma unroll
+        for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
+        if (WITH_Q) {
+            double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
+            double a0 = d0 * d0, a1 = d1 * d1;
+#pragma unroll
+            for (int k = 1; k < NANT; k++) {
+                d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
+                a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
+            }
+            if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
+            else { const double wi = shepard_w(a0, pk); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
+            if (second) {
+                if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
+                else { const double wi = shepard_w(a1, pk); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; }
+            }
+        }
+        double s0, s1;
+        {
+            double d0 = qs[0] - v[0].x, d1 = qs[0] - v[0].y;
+            s0 = d0 * d0; s1 = d1 * d1;
+#pragma unroll
+            for (int k = 1; k < NS; k++) {
+                d0 = qs[k] - v[k].x; d1 = qs[k] - v[k].y;
+                s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
+            }
+        }
+        const double2 va = v[NS];
+        if (!second) s1 = 1.0e300;                 // no rule r + 1: weight (1e300)^(-P/2) underflows to exactly 0
+        if (__builtin_amdgcn_ballot_w64(s0 == 0.0 || s1 == 0.0) != 0ull) {      // rare: a rule with exactly this state
+            for (int a = 0; a < A; a++) {
+                const double ava = s.ave[a];
+                if (s0 == 0.0 && ava == va.x) atomicMin(&s.hit[a], (unsigned)r);           // d^2 = (av - va)^2 + 0 == 0  <=>  av == va
+                if (s1 == 0.0 && ava == va.y) atomicMin(&s.hit[a], (unsigned)(r + 1));
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < AMAX / G; g++) {
+            if (G * g < A) {
+#pragma unroll
+                for (int j = 0; j < G; j++) concl_pair_nohit(av[G * g + j], va, s0, s1, c, pk, sv[G * g + j], sw[G * g + j]);
+            }
+        }
+    }
+    if (WITH_Q) {
+        qres->hit = blk_min<BLOCK>(qbest, red);
+        qres->vagc = blk_sum<BLOCK>(qv, red);
+        qres->ws = blk_sum<BLOCK>(qw, red);
+        qres->tracked = false;
+    }
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+        if (a < A) {
+            const double tv = wave_sum_f64(sv[a]), tw = wave_sum_f64(sw[a]);
+            if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < A) {
+        const int a = threadIdx.x;
+        double tv = s.v[0][a], tw = s.w[0][a];
+        for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; }
+        const unsigned th = s.hit[a];
+        s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int a = 1; a < A; a++) if (s.actconc[best] < s.actconc[a]) best = a;   // strict <: first maximum wins
         s.best = best;
     }
     __syncthreads();
