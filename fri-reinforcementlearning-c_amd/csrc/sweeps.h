@@ -508,6 +508,27 @@ __device__ __forceinline__ bool wave_no_state_hit(bool second, double s0, double
     return FRIRL_GBA_FASTPATH && __builtin_amdgcn_ballot_w64(!second || s0 == 0.0 || s1 == 0.0) == 0ull;
 }
 
+// Exact hits of the greedy sweeps, recorded OUTSIDE the hot loop.  An action that has an exact hit anywhere takes its conclusion from
+// that rule and its Shepard sums are discarded (FIVEVagConcl_FRIRL_BestAct.c:89-93), so the sweeps run ONE branch-free loop body that lets
+// rsq(0) poison the two sums of exactly that action, and only note the hit: d^2 = (av - va)^2 + s == 0 needs a zero state part s -- rare
+// -- and then means av == va.  The side path scans the actions and takes an LDS atomic min (first hit = lowest rule index).  No per-action
+// hit register, compare, branch or select.  The odd tail (r + 1 == R) gets a huge state part instead of a branch: its weight
+// (1e300)^(-P/2) underflows to exactly 0 and adds +0 to both sums.
+#ifndef FRIRL_GBA_POISON
+#define FRIRL_GBA_POISON 1
+#endif
+static constexpr double NO_RULE_STATE_PART = 1.0e300;
+__device__ __forceinline__ void note_state_hits(unsigned *hit_s, const double *ave_s, int A, double s0, double s1, const double2 &va, unsigned r)
+{
+    if (__builtin_amdgcn_ballot_w64(s0 == 0.0 || s1 == 0.0) != 0ull) {
+        for (int a = 0; a < A; a++) {
+            const double ava = ave_s[a];
+            if (s0 == 0.0 && ava == va.x) atomicMin(&hit_s[a], r);
+            if (s1 == 0.0 && ava == va.y) atomicMin(&hit_s[a], r + 1u);
+        }
+    }
+}
+
 template <int NANT, int AMAX, int BLOCK, class COLS, class POW>
 __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1], POW p, int A,
                          GbaScratch<AMAX, BLOCK> &s)
@@ -516,13 +537,29 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
     double sv[AMAX], sw[AMAX], av[AMAX];
     unsigned sh[AMAX];
 #pragma unroll
-    for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; av[a] = (a < A) ? s.ave[a] : 0.0; }
+    for (int a = 0; a < AMAX; a++) {
+        sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT;
+        av[a] = FRIRL_GBA_POISON ? wave_uniform(s.ave[a < A ? a : 0]) : ((a < A) ? s.ave[a] : 0.0);      // poison form: in SGPRs
+    }
+#if FRIRL_GBA_POISON
+    if ((int)threadIdx.x < AMAX) s.hit[threadIdx.x] = FRIRL_HIP_NO_HIT;
+    __syncthreads();
+    const auto pk = pin_pow(p);
+#endif
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double s0 = 0.0, s1 = 0.0;
         if (NS > 0) sq_dist2<(NS > 0 ? NS : 1)>(cols, r, qs, s0, s1);
         const double2 va = cols.pair(NS, r);
         const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
+#if FRIRL_GBA_POISON
+        if (!second) s1 = NO_RULE_STATE_PART;
+        note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
+#pragma unroll
+        for (int a = 0; a < AMAX; a++)
+            if (a < A) concl_pair_nohit(av[a], va, s0, s1, c, pk, sv[a], sw[a]);
+        continue;
+#endif
 #pragma unroll
         for (int a = 0; a < AMAX; a++) {
             if (a < A) {
@@ -560,6 +597,7 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
         double tv = s.v[0][a], tw = s.w[0][a];
         unsigned th = s.h[0][a];
         for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; th = min(th, s.h[w][a]); }
+        if (FRIRL_GBA_POISON) th = s.hit[a];
         s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
     }
     __syncthreads();
@@ -589,7 +627,15 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     double sv[AMAX], sw[AMAX], av[AMAX];
     unsigned sh[AMAX];
 #pragma unroll
-    for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; av[a] = (a < A) ? s.ave[a] : 0.0; }
+    for (int a = 0; a < AMAX; a++) {
+        sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT;
+        av[a] = FRIRL_GBA_POISON ? wave_uniform(s.ave[a < A ? a : 0]) : ((a < A) ? s.ave[a] : 0.0);      // poison form: in SGPRs
+    }
+#if FRIRL_GBA_POISON
+    if ((int)threadIdx.x < AMAX) s.hit[threadIdx.x] = FRIRL_HIP_NO_HIT;
+    __syncthreads();
+    const auto pk = pin_pow(p);
+#endif
     unsigned qbest = FRIRL_HIP_NO_HIT;
     double qv = 0.0, qw = 0.0;
     // software prefetch: the loads of the NEXT pair of rules are issued before the ~100 FP64 instructions of the current
@@ -655,6 +701,13 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 }
             }
             const double2 va = v[NS];
+#if FRIRL_GBA_POISON
+            if (!second) s1 = NO_RULE_STATE_PART;
+            note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
+#pragma unroll
+            for (int a = 0; a < AMAX; a++)
+                if (a < A) concl_pair_nohit(av[a], va, s0, s1, c, pk, sv[a], sw[a]);
+#else
 #pragma unroll
             for (int a = 0; a < AMAX; a++) {
                 if (a < A) {
@@ -668,6 +721,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                     }
                 }
             }
+#endif
         }
     }
     qres.hit = blk_min<BLOCK>(qbest, red);
@@ -688,6 +742,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
         double tv = s.v[0][a], tw = s.w[0][a];
         unsigned th = s.h[0][a];
         for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; th = min(th, s.h[w][a]); }
+        if (FRIRL_GBA_POISON) th = s.hit[a];
         s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
     }
     __syncthreads();
@@ -779,14 +834,8 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
             }
         }
         const double2 va = v[NS];
-        if (!second) s1 = 1.0e300;                 // no rule r + 1: weight (1e300)^(-P/2) underflows to exactly 0
-        if (__builtin_amdgcn_ballot_w64(s0 == 0.0 || s1 == 0.0) != 0ull) {      // rare: a rule with exactly this state
-            for (int a = 0; a < A; a++) {
-                const double ava = s.ave[a];
-                if (s0 == 0.0 && ava == va.x) atomicMin(&s.hit[a], (unsigned)r);           // d^2 = (av - va)^2 + 0 == 0  <=>  av == va
-                if (s1 == 0.0 && ava == va.y) atomicMin(&s.hit[a], (unsigned)(r + 1));
-            }
-        }
+        if (!second) s1 = NO_RULE_STATE_PART;
+        note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
 #pragma unroll
         for (int g = 0; g < AMAX / G; g++) {
             if (G * g < A) {
