@@ -302,12 +302,29 @@ class Bench:
                "moved_bytes_per_step": moved, "moved_GBps": moved / (ems * 1e-3) / 1e9, "moved_frac": moved / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "contract_bytes_per_step": float(E) * (2.0 * R * (nant + 1) * 8 + R * 8),    # SURVEY 8d U2 (the reference's three sweeps, f64)
                "rule_action_evals_per_s": float(E) * R * (w["A"] + 1) / (ems * 1e-3),
+               "fp64_issue": fp64_issue(E, R, nant, w["A"], ems),
                "stats_allreduce": {"envs": st.envs, "mean_reward": st.mean_reward, "mean_rules": st.mean_rules, "steps_sum": st.steps_sum,
                                    "episodes_done": st.success, "reward_min": st.reward_min, "reward_max": st.reward_max},
                "last_step_outcomes_rank0": dict(zip(["inactive", "exact", "spread", "inserted", "skipped", "full"], status)),
                "note": "moved_* = one pass over the rule-base slabs per step (the fused sweep; compressed antecedents where the step kernel uses "
-                       "them); the kernel is FP64-issue bound at these shapes (A+1 Shepard sums per rule), not HBM bound"}
+                       "them); fp64_issue = the step's second roofline: algorithmic FP64 vector-instruction slots of the fused sweep / the "
+                       "chip's FP64 vector issue rate (many actions: issue-bound; 3 actions at 65 536 rules: between the two)"}
         return leg
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6        # MI355X FP64 vector peak (FMA = 2 flop): 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x 2
+
+
+def fp64_issue(E, R, nant, A, ms):
+    """FP64-issue roofline of the fused step.  Algorithmic slots per rule (one slot = one FP64 vector instruction of one lane;
+    v_rsq_f64 issues in 3.4 slots, profiles/r02_valu_cost.txt): per conclusion (A greedy + 1 pending) 2 for the squared distance,
+    3.4 + 7 for the Shepard weight (rsq + series + power, sweeps.h: shepard_series), 2 for the two sums = 14.4; plus the state part
+    (sub + fma per state dimension) and the rest of the pending update's full distance."""
+    slots_per_rule = 14.4 * (A + 1) + 2.0 * (nant - 1) + 2.0 * (nant - 1)
+    peak = FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0          # lane-instructions per second
+    achieved = float(E) * R * slots_per_rule / (ms * 1e-3)
+    return {"slots_per_rule": slots_per_rule, "achieved_lane_instr_per_s": achieved, "peak_lane_instr_per_s": peak, "frac": achieved / peak,
+            "peak_source": "FP64 vector 78.6 TFLOP/s (half the FP32 vector peak of MI355X_MICROARCH.md: 16 lanes per clock and SIMD at 2.4 GHz) = 3.93e13 lane-instructions/s; a v_fma_f64 stream alone reaches 0.82 of it (profiles/r02_valu_cost.txt)"}
 
 
 def learning_and_evaluation(B, w, world, rank):

@@ -82,6 +82,51 @@ def test_get_best_action(nant, U, R, E, A):
             assert abs(ac[best[e]] - srt[-1]) <= 1e-9 * max(1.0, abs(srt[-1]))
 
 
+@pytest.mark.parametrize("nant,U,A,compressed", [(5, 1001, 21, True), (5, 1001, 21, False), (3, 41, 9, False), (4, 101, 10, True), (5, 41, 13, False),
+                                                 (3, 101, 24, True), (5, 101, 25, False), (2, 41, 32, False)])
+def test_get_best_action_many_actions(nant, U, A, compressed):
+    """More than 8 actions at >= 256 environments (the 256-thread kernels): 9..24 actions keep every accumulator pair in registers
+    (sweep_gba_many: A rounded up to a multiple of three, exact hits recorded in the side path), more use the action-parallel waves
+    (sweep_gba_wide); `no_many` forces the latter.  Both against the oracle: arg-max exact, exact-hit conclusions bit-exact, interpolated
+    ones within RTOL; odd rule counts, empty-ish rule bases and hits on the last rule included."""
+    import torch
+    import frirl_amd
+    E, R = 259, 2600 if compressed else 700
+    b = Batch(nant, U, R, E, A=A, seed=11 + A, ragged=True)
+    b.nrules[b.nrules == 0] = 1
+    b.nrules[1] = 1
+    b.nrules[2] = R - 1 if (R - 1) % 2 else R - 2          # an odd count: the tail pair has no second rule
+    ave, _ = b.action_ve()
+    x = b.queries(seed=A, hit_fraction=0.6)
+    states = np.ascontiguousarray(x[:, : nant - 1])
+    prob = b.to_device(compressed=compressed)
+    got = {}
+    for nm in (0, 1):
+        old = frirl_amd.set_option("no_many", nm)
+        try:
+            actconc, best = prob.get_best_action(dev(states), dev(ave))
+            torch.cuda.synchronize()
+        finally:
+            frirl_amd.set_option("no_many", old)
+        got[nm] = (actconc.cpu().numpy(), best.cpu().numpy())
+    hits = 0
+    for nm in (0, 1):
+        actconc, best = got[nm]
+        for e in list(range(0, E, 7)) + [1, 2]:
+            f = b.five(e)
+            bo, ac = f.best_action(states[e], ave)
+            assert rel(actconc[e], ac).max() <= RTOL, (nm, e, actconc[e], ac)
+            n = int(b.nrules[e])
+            exact = np.isin(ac, b.rb[e, nant, :n]) & (actconc[e] == ac)
+            hits += int(exact.sum())
+            srt = np.sort(ac)
+            if (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
+                assert best[e] == bo, (nm, e, actconc[e], ac)
+    assert hits > 0, "no exact hit exercised"
+    # the two forms sum in different orders: same arg-max wherever the oracle's maximum is clear (checked above), values within RTOL
+    assert rel(got[0][0], got[1][0]).max() <= 10 * RTOL
+
+
 def test_get_best_action_exact_ties_pick_first():
     """The observed state hits one rule per action with equal consequents => exactly tied Q values =>
     the FIRST maximum (index 0) wins (reference src/inl/max.inl:21, strict <)."""
