@@ -142,6 +142,7 @@ SIGNATURES = {
     "frirl_hip_multi_create": (C.c_void_p, [C.c_void_p, C.c_int64, C.c_int32]),
     "frirl_hip_multi_destroy": (None, [C.c_void_p]),
     "frirl_hip_multi_train": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "frirl_hip_multi_train_merged": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "frirl_hip_multi_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "frirl_hip_multi_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "frirl_hip_multi_get_rulebase": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), _DP, _DP]),

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <vector>
 
+#include "batch_internal.h"
 #include "device_common.h"
 
 using namespace frirl_host;
@@ -266,48 +267,97 @@ extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strateg
 // (1) every agent id >= 1 takes over the master's (agent 0's) rules -- all receivers in ONE launch; (2) the master takes over the
 // rules of agent 1, 2, ... one after the other (sequential by definition: each merge changes the master).  Agents whose rule base
 // is complete ("epended": converged[]) do not send, as in the reference (:432,:444).
-extern "C" int frirl_hip_batch_merge_round(frirl_hip_batch *b, int32_t *full_agents)
+// ---- the pieces of a merge round (batch_internal.h; also strung together across devices by multi.hip) --------------------------
+namespace frirl_host {
+
+BatchView batch_view(frirl_hip_batch *b)
 {
-    if (!b) { set_error("frirl_hip_batch_merge_round: NULL batch"); return FRIRL_HIP_EINVAL; }
+    return BatchView{b->nant, b->maxR, b->E, b->device, b->s, b->d_rant, b->d_rb, b->d_nrules, b->d_converged};
+}
+
+int batch_merge_prepare(frirl_hip_batch *b, std::vector<int32_t> &conv)
+{
     BCHK(hipSetDevice(b->device), "hipSetDevice");
-    const size_t n = b->nant, M = b->maxR, E = b->E;
-    if (full_agents) *full_agents = 0;
-    if (E < 2) return FRIRL_HIP_OK;
+    const size_t M = b->maxR, E = b->E;
     if (!b->d_weights) {
         if (!dalloc(&b->d_weights, E * M) || !dalloc(&b->d_active, E) || !dalloc(&b->d_full, E)) { set_error("frirl_hip_batch_merge_round: allocation failed"); return FRIRL_HIP_ELAUNCH; }
     }
-    b->h_i.resize(E);
-    BCHK(hipMemcpyAsync(b->h_i.data(), b->d_converged, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "converged download");
+    conv.resize(E);
+    BCHK(hipMemcpyAsync(conv.data(), b->d_converged, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "converged download");
     BCHK(hipStreamSynchronize(b->s), "merge sync");
-    std::vector<int32_t> conv(b->h_i.begin(), b->h_i.begin() + E);
-    int rc;
     // the receivers' FIVERB.weights as the learning episodes left them (the reference's merge starts from that array)
-    if ((rc = frirl_hip_weights_from_spread(&b->t, &b->rb, b->agent.p, &b->envs, b->d_weights, b->s))) return rc;
+    return frirl_hip_weights_from_spread(&b->t, &b->rb, b->agent.p, &b->envs, b->d_weights, b->s);
+}
+
+int batch_merge_into_agents(frirl_hip_batch *b, const frirl_hip_sender *snd, bool skip_first)
+{
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    const size_t E = b->E;
+    if (skip_first && E < 2) return FRIRL_HIP_OK;
+    std::vector<uint8_t> act(E, 1);
+    if (skip_first) act[0] = 0;
+    BCHK(hipMemcpyAsync(b->d_active, act.data(), E, hipMemcpyHostToDevice, b->s), "active upload");
+    const int rc = frirl_hip_merge_rb(&b->t, &b->rb, &b->agent, b->d_rant, snd, b->d_weights, b->d_active, b->d_full, b->s);
+    if (rc) return rc;
+    BCHK(hipStreamSynchronize(b->s), "merge sync");              // `act` must outlive the upload
+    return FRIRL_HIP_OK;
+}
+
+int batch_merge_into_first(frirl_hip_batch *b, const frirl_hip_sender *snd)
+{
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    frirl_hip_rulebases master = b->rb;
+    master.E = 1;
+    return frirl_hip_merge_rb(&b->t, &master, &b->agent, b->d_rant, snd, b->d_weights, nullptr, b->d_full, b->s);
+}
+
+frirl_hip_sender batch_sender(frirl_hip_batch *b, int id)
+{
+    const size_t n = b->nant, M = b->maxR;
     frirl_hip_sender snd;
     memset(&snd, 0, sizeof snd);
     snd.rule_stride = 1; snd.dim_stride = (int64_t)M;
-    if (!conv[0]) {                                                   // (1) master -> every other agent
-        std::vector<uint8_t> act(E, 1);
-        act[0] = 0;
-        BCHK(hipMemcpyAsync(b->d_active, act.data(), E, hipMemcpyHostToDevice, b->s), "active upload");
-        snd.rant = b->d_rant; snd.rconc = b->d_rb + n * M; snd.S_dev = b->d_nrules;
-        if ((rc = frirl_hip_merge_rb(&b->t, &b->rb, &b->agent, b->d_rant, &snd, b->d_weights, b->d_active, b->d_full, b->s))) return rc;
-        BCHK(hipStreamSynchronize(b->s), "merge sync");              // `act` must outlive the upload
-    }
-    frirl_hip_rulebases master = b->rb;                                // (2) agent id -> master, id ascending
-    master.E = 1;
-    for (size_t id = 1; id < E; id++) {
-        if (conv[id]) continue;
-        snd.rant = b->d_rant + id * n * M; snd.rconc = b->d_rb + (id * (n + 1) + n) * M; snd.S_dev = b->d_nrules + id;
-        if ((rc = frirl_hip_merge_rb(&b->t, &master, &b->agent, b->d_rant, &snd, b->d_weights, nullptr, b->d_full, b->s))) return rc;
-    }
+    snd.rant = b->d_rant + (size_t)id * n * M;
+    snd.rconc = b->d_rb + ((size_t)id * (n + 1) + n) * M;
+    snd.S_dev = b->d_nrules + id;
+    return snd;
+}
+
+int batch_merge_finish(frirl_hip_batch *b, int32_t *full_agents)
+{
+    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    const size_t E = b->E;
+    b->h_i.resize(E);
     BCHK(hipMemcpyAsync(b->h_i.data(), b->d_nrules, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "nrules download");
     BCHK(hipStreamSynchronize(b->s), "merge sync");
     if (full_agents) for (size_t e = 0; e < E; e++) *full_agents += b->h_i[e] >= b->maxR;
     // the merged rule bases are new starting points: the "same as the previous episode" test restarts from them (prev_* refreshed)
-    if ((rc = frirl_hip_convergence_refresh(&b->rb, b->nant, &b->conv, b->s))) return rc;
+    const int rc = frirl_hip_convergence_refresh(&b->rb, b->nant, &b->conv, b->s);
+    if (rc) return rc;
     BCHK(hipStreamSynchronize(b->s), "merge sync");
     return FRIRL_HIP_OK;
+}
+
+}  // namespace frirl_host
+
+extern "C" int frirl_hip_batch_merge_round(frirl_hip_batch *b, int32_t *full_agents)
+{
+    if (!b) { set_error("frirl_hip_batch_merge_round: NULL batch"); return FRIRL_HIP_EINVAL; }
+    if (full_agents) *full_agents = 0;
+    if (b->E < 2) return FRIRL_HIP_OK;
+    std::vector<int32_t> conv;
+    int rc = batch_merge_prepare(b, conv);
+    if (rc) return rc;
+    if (!conv[0]) {                                                   // (1) master -> every other agent
+        const frirl_hip_sender snd = batch_sender(b, 0);
+        if ((rc = batch_merge_into_agents(b, &snd, true))) return rc;
+    }
+    for (int id = 1; id < b->E; id++) {                               // (2) agent id -> master, id ascending
+        if (conv[id]) continue;
+        const frirl_hip_sender snd = batch_sender(b, id);
+        if ((rc = batch_merge_into_first(b, &snd))) return rc;
+    }
+    return batch_merge_finish(b, full_agents);
 }
 
 // frirl_omp_run's loop (frirl_agent.c:424-462) for the agents of this batch: rounds of `chunk - 1` episodes per agent

@@ -1,0 +1,34 @@
+// batch_internal.h -- the pieces of a rule-base merge round of ONE frirl_hip_batch (batch.hip), shared with the multi-device runner
+// (multi.hip), which strings them together across devices.  Not part of the C ABI.
+#pragma once
+
+#include <vector>
+
+#include "device_common.h"
+
+struct frirl_hip_batch;
+
+namespace frirl_host {
+
+struct BatchView {                 // what the multi-device exchange needs to see of a batch
+    int nant, maxR, E, device;
+    hipStream_t s;
+    double *d_rant;                // [E][nant][maxR] raw antecedents
+    double *d_rb;                  // [E][nant+1][maxR] VE antecedents + consequents
+    int32_t *d_nrules, *d_converged;
+};
+BatchView batch_view(frirl_hip_batch *b);
+
+// start of a merge round: the receivers' FIVERB.weights as learning left them (frirl_hip_weights_from_spread); conv = the agents'
+// "rule base complete" flags (host copy)
+int batch_merge_prepare(frirl_hip_batch *b, std::vector<int32_t> &conv);
+// every agent of the batch (but agent 0 when skip_first) takes over the sender's rules: one launch of frirl_hip_merge_rb
+int batch_merge_into_agents(frirl_hip_batch *b, const frirl_hip_sender *snd, bool skip_first);
+// agent 0 of the batch (the master) takes over the sender's rules
+int batch_merge_into_first(frirl_hip_batch *b, const frirl_hip_sender *snd);
+// sender descriptor for agent id of this batch (a row set of its own SoA store)
+frirl_hip_sender batch_sender(frirl_hip_batch *b, int id);
+// end of a round: *full_agents += agents at capacity; the convergence bookkeeping restarts from the merged rule bases
+int batch_merge_finish(frirl_hip_batch *b, int32_t *full_agents);
+
+}  // namespace frirl_host

@@ -514,6 +514,10 @@ __device__ __forceinline__ bool wave_no_state_hit(bool second, double s0, double
 // -- and then means av == va.  The side path scans the actions and takes an LDS atomic min (first hit = lowest rule index).  No per-action
 // hit register, compare, branch or select.  The odd tail (r + 1 == R) gets a huge state part instead of a branch: its weight
 // (1e300)^(-P/2) underflows to exactly 0 and adds +0 to both sums.
+#ifndef FRIRL_STEP_PREFETCH
+#define FRIRL_STEP_PREFETCH 1
+#endif
+static constexpr int STEP_PREFETCH = FRIRL_STEP_PREFETCH;      // rule pairs requested ahead per lane in sweep_gba_q
 #ifndef FRIRL_GBA_POISON
 #define FRIRL_GBA_POISON 1
 #endif
@@ -640,21 +644,26 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     double qv = 0.0, qw = 0.0;
     // software prefetch: the loads of the NEXT pair of rules are issued before the ~100 FP64 instructions of the current
     // pair, so a wave does not sit on s_waitcnt at the top of every iteration
-    typename COLS::raw_t nraw[NANT];
-    double2 nc = {0.0, 0.0};
-    {
-        const int r0 = 2 * (int)threadIdx.x;
+    // PD stages in flight (FRIRL_STEP_PREFETCH): with one stage a 256-thread workgroup has 9 KB requested ahead, ~45 KB per CU --
+    // about what 8 TB/s x 1.5 us of loaded HBM latency needs chip-wide, nothing to spare
+    constexpr int PD = STEP_PREFETCH;
+    typename COLS::raw_t nraw[PD][NANT];
+    double2 nc[PD];
+#pragma unroll
+    for (int u = 0; u < PD; u++) {
+        const int r0 = 2 * (int)threadIdx.x + u * 2 * BLOCK;
+        nc[u] = double2{0.0, 0.0};
         if (r0 < R) {
 #pragma unroll
-            for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r0);
-            nc = load_col2(qcol + r0);
+            for (int k = 0; k < NANT; k++) nraw[u][k] = cols.raw(k, r0);
+            nc[u] = load_col2(qcol + r0);
         }
     }
     double T = 0.0;
     // tracked form: wave-uniform trip count, because spread_track is a wave-level operation with ONE call site that every
     // lane of the wave reaches together; lanes whose last pair lies past R skip the arithmetic of that turn
     const int r_lim = TRACK ? wave_uniform_limit(R) : R;
-    for (int r = 2 * (int)threadIdx.x; r < r_lim; r += 2 * BLOCK) {
+    auto rule_pair = [&](const int r, typename COLS::raw_t (&sraw)[NANT], double2 &sc) {
         const bool live = !TRACK || r < R;
         const bool second = (r + 1 < R);
         double2 v[NANT];
@@ -663,12 +672,12 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
         if (live) {
             typename COLS::raw_t raw[NANT];
 #pragma unroll
-            for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
-            c = nc;
-            if (r + 2 * BLOCK < R) {
+            for (int k = 0; k < NANT; k++) raw[k] = sraw[k];
+            c = sc;
+            if (r + PD * 2 * BLOCK < R) {
 #pragma unroll
-                for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * BLOCK);
-                nc = load_col2(qcol + r + 2 * BLOCK);
+                for (int k = 0; k < NANT; k++) sraw[k] = cols.raw(k, r + PD * 2 * BLOCK);
+                sc = load_col2(qcol + r + PD * 2 * BLOCK);
             }
 #pragma unroll
             for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
@@ -722,6 +731,13 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 }
             }
 #endif
+        }
+    };
+    for (int r = 2 * (int)threadIdx.x; r < r_lim; r += PD * 2 * BLOCK) {
+#pragma unroll
+        for (int u = 0; u < PD; u++) {
+            const int ru = r + u * 2 * BLOCK;
+            if (ru < r_lim) rule_pair(ru, nraw[u], nc[u]);       // tracked form: wave-uniform (r_lim is a multiple of 128)
         }
     }
     qres.hit = blk_min<BLOCK>(qbest, red);

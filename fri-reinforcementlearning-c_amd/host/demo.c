@@ -37,6 +37,10 @@ int main(int argc, char **argv)
         else if (fargc < 15) fargv[fargc++] = argv[i];
     }
     frirl_parse_cmdline(&fr, fargc, fargv);
+    if (agents > 0 && merge && gpus >= 0) {       /* rule-base exchange across devices */
+        snprintf(name, sizeof name, "%s.multi.merged.frirlrb.txt", env);
+        return frirl_demo_multi_merged_run(env, agents, gpus, max_episodes > 0 ? max_episodes : fr.max_episodes, name, 1) >= 0 ? 0 : 3;
+    }
     if (agents > 0 && merge) {
         snprintf(name, sizeof name, "%s.merged.frirlrb.txt", env);
         return frirl_demo_merged_run(env, agents, max_episodes > 0 ? max_episodes : fr.max_episodes, name, 1) >= 0 ? 0 : 3;

@@ -391,6 +391,47 @@ int frirl_demo_merged_run(const char *env, int agents, int max_episodes, const c
     return rounds;
 }
 
+/* The same over `gpus` devices (0 = all): frirl_hip_multi_train_merged -- the master's rule list is broadcast to every device, the devices
+ * send their agents' rule lists to device 0 (RCCL), the master takes them over in global agent order.  Returns the merge rounds, or -1. */
+int frirl_demo_multi_merged_run(const char *env, int agents, int gpus, int max_episodes, const char *out_txt, int verbose)
+{
+    int nant = 0, episodes = 0, rounds = 0, rc;
+    int32_t ng = 0, ver = 0;
+    frirl_hip_batch_desc d;
+    struct demo_desc_mem mm;
+    frirl_hip_multi *m;
+    frirl_hip_batch_stats_t st;
+    double *start;
+    if (demo_desc_build(env, agents, &d, &mm, &nant) != 0) return -1;
+    start = malloc(sizeof(double) * (size_t)agents * (nant - 1));
+    if (!start || frirl_hip_gen_def_states(d.rant0, d.R0, nant, agents, d.agent.values_def, start) != 0) return -1;
+    d.start_states = start;
+    m = frirl_hip_multi_create(&d, agents, gpus);
+    if (!m) five_dropin_fatal("frirl_demo_multi_merged_run(create)", FRIRL_HIP_ENODEV);
+    rc = frirl_hip_multi_train_merged(m, max_episodes, 10, &episodes, &rounds);
+    if (rc) five_dropin_fatal("frirl_demo_multi_merged_run(train)", rc);
+    rc = frirl_hip_multi_stats(m, &st);
+    if (rc) five_dropin_fatal("frirl_demo_multi_merged_run(stats)", rc);
+    frirl_hip_multi_info(m, &ng, &ver, NULL, NULL);
+    if (verbose)
+        printf("merged %s: gpus %d (RCCL %d) agents %lld episodes %d merge-rounds %d converged %lld env-steps %lld mean-rules %.3f mean-reward %.6f\n", env,
+               (int)ng, (int)ver, (long long)st.agents, episodes, rounds, (long long)st.converged, (long long)st.total_env_steps, st.rules_sum / st.agents,
+               st.reward_sum / st.agents);
+    if (st.full_agents > 0)
+        fprintf(stderr, "Warning: %lld of %lld rule bases are at their capacity of %d rules: further rule insertions were refused\n",
+                (long long)st.full_agents, (long long)st.agents, (int)d.maxR);
+    if (out_txt) {
+        int32_t R = 0;
+        double *rant = malloc(sizeof(double) * 1024 * nant), *rconc = malloc(sizeof(double) * 1024);
+        if (!rant || !rconc || frirl_hip_multi_get_rulebase(m, 0, &R, rant, rconc) != 0 || dump_rule_base_txt(out_txt, nant, R, rant, rconc) != 0) return -1;
+        free(rant); free(rconc);
+    }
+    frirl_hip_multi_destroy(m);
+    demo_desc_free(&mm);
+    free(start);
+    return rounds;
+}
+
 int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int reduce_strategy, const char *load_bin, const char *save_bin,
                             const char *out_txt, int verbose)
 {

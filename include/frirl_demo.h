@@ -33,6 +33,8 @@ int frirl_demo_batch_run_ex(const char *env, int agents, int max_episodes, int r
 /* many agents WITH the reference's rule-base exchange (frirl_omp_run: chunks of 9 episodes, merge_rb in both directions after each,
  * start states from gen_def_states) on one GPU; out_txt = the master's rule base.  Returns the number of merge rounds, or -1. */
 int frirl_demo_merged_run(const char *env, int agents, int max_episodes, const char *out_txt, int verbose);
+/* the same with the agents sharded over `gpus` devices (0 = all) and the rule-base exchange over RCCL (frirl_hip_multi_train_merged) */
+int frirl_demo_multi_merged_run(const char *env, int agents, int gpus, int max_episodes, const char *out_txt, int verbose);
 int frirl_demo_multi_run(const char *env, int agents, int gpus, int max_episodes, const char *out_txt, int verbose);
 
 #endif

@@ -487,10 +487,10 @@ int frirl_hip_gen_def_states(const double *master_rant, int32_t R, int32_t nant,
 
 /* =================================================================================================
  * Many agents over several GPUs of one node, from plain C (the reference's frirl_omp_run / frirl_mpi_run shape,
- * src/frirl/frirl_agent.c:294-467; the rule-base exchange stays inside one device's batch): `total_agents` agents are sharded over `ngpus` visible
+ * src/frirl/frirl_agent.c:294-467): `total_agents` agents are sharded over `ngpus` visible
  * devices by GLOBAL environment id (frirl_hip_shard: balanced contiguous partition; RNG streams and start states are keyed by
- * the global id, so trajectories do not depend on the sharding), one frirl_hip_batch and one host thread per device, no
- * data-path collective.  The only exchange is the per-episode report (sums of reward / steps / rules / converged, reward
+ * the global id, so trajectories do not depend on the sharding), one frirl_hip_batch and one host thread per device.  Learning has no
+ * data-path collective: the only exchange is the per-episode report (sums of reward / steps / rules / converged, reward
  * min / max; frirl_sequential_run.c:74-80): RCCL all-reduce over xGMI, one communicator per device in this single process
  * (ncclCommInitAll).  RCCL is loaded at first use (dlopen "librccl.so.1"); the library does not link against it.
  * ================================================================================================= */
@@ -503,6 +503,12 @@ frirl_hip_multi *frirl_hip_multi_create(const frirl_hip_batch_desc *d, int64_t t
 void frirl_hip_multi_destroy(frirl_hip_multi *m);
 /* frirl_sequential_run's construct loop on every device at once; stops when the ALL-REDUCED report says every agent converged */
 int frirl_hip_multi_train(frirl_hip_multi *m, int32_t max_episodes, int32_t *episodes_run);
+/* The many-agent mode WITH the rule-base exchange across the devices (frirl_omp_run / frirl_mpi_run, frirl_agent.c:424-462): rounds of
+ * chunk - 1 episodes per agent, then one merge round -- the master (global agent 0, device 0) is broadcast to every device (RCCL broadcast)
+ * and taken over by all other agents, the devices send their agents' rule lists to device 0 (RCCL send / receive) and the master takes
+ * them over in GLOBAL agent order -- until the master's rule base is complete or max_episodes - 1 episodes have run.  With one device
+ * this is frirl_hip_batch_train_merged.  Give the agents different start states (frirl_hip_gen_def_states -> d->start_states). */
+int frirl_hip_multi_train_merged(frirl_hip_multi *m, int32_t max_episodes, int32_t chunk, int32_t *episodes_run, int32_t *rounds);
 /* the report of the whole job (all-reduced over the devices) */
 int frirl_hip_multi_stats(frirl_hip_multi *m, frirl_hip_batch_stats_t *out);
 /* *ngpus devices in use, RCCL version code, per-device shard [start, count) (arrays of >= *ngpus entries, or NULL) */

@@ -54,3 +54,34 @@ def test_c_level_multi_gpu_runner_on_one_device(env, rules, steps, tmp_path):
     assert (mine[:, :-1] == np.array(f.rant[:rules])).all()
     rel = np.abs(mine[:, -1] - f.rconc[:rules]) / np.maximum(np.abs(f.rconc[:rules]), 1e-9)
     assert rel.max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,agents,max_episodes", [("mountaincar", 6, 22), ("acrobot", 5, 12)])
+def test_c_level_rule_base_exchange_across_devices_on_one_device(env, agents, max_episodes, tmp_path):
+    """`frirl_demo --agents N --gpus 1 --merge`: the many-agent loop WITH the rule-base exchange through frirl_hip_multi_train_merged (master
+    broadcast with ncclBroadcast, the staged master list as the sender, the report's "master complete" flag all-reduced) must reproduce
+    `frirl_demo --agents N --merge` (frirl_hip_batch_train_merged, itself checked against the oracle loop in test_hip_merge.py) bit for
+    bit: same episodes, same rounds, identical master rule base.  (More than one device cannot run on the test box; the peer path --
+    ncclSend / ncclRecv of the shards' rule lists -- differs only in where the sender rows lie.)"""
+    frirl_amd.build()
+    demo = os.path.join(frirl_amd.PKG_DIR, "lib", "frirl_demo")
+    a = subprocess.run([demo, "--env", env, "--agents", str(agents), "--merge", "--max-episodes", str(max_episodes)], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=900)
+    b = subprocess.run([demo, "--env", env, "--agents", str(agents), "--gpus", "1", "--merge", "--max-episodes", str(max_episodes)], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=900)
+    assert a.returncode == 0, a.stdout[-2000:] + a.stderr[-2000:]
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+    assert "gpus 1 (RCCL" in b.stdout, b.stdout
+
+    def fields(out):
+        line = [ln for ln in out.splitlines() if ln.startswith("merged ")][-1]
+        tok = line.split()
+        return {k: tok[tok.index(k) + 1] for k in ("agents", "episodes", "merge-rounds", "converged", "env-steps", "mean-rules", "mean-reward")}
+
+    fa, fb = fields(a.stdout), fields(b.stdout)
+    assert fa == fb, (fa, fb)
+    assert int(fa["merge-rounds"]) >= 1
+    one = np.loadtxt(tmp_path / f"{env}.merged.frirlrb.txt", dtype=np.float64, ndmin=2)
+    multi = np.loadtxt(tmp_path / f"{env}.multi.merged.frirlrb.txt", dtype=np.float64, ndmin=2)
+    assert one.shape == multi.shape and (one.view(np.uint64) == multi.view(np.uint64)).all()
