@@ -74,6 +74,22 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// N independent sums in ONE pass of the butterfly: the N cross-lane moves of a step are issued back to back and waited for once.
+// One after the other (wave_sum_f64 in a loop) every step pays the full ds_bpermute latency -- ~12 us for the 42 sums of a 21-action
+// greedy sweep, measured as the largest part of a single-rule-base step at ~200 rules.  Same additions in the same order per value.
+template <int N>
+__device__ __forceinline__ void wave_sum_f64_n(double (&v)[N])
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double t[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) t[i] = __shfl_xor(v[i], off, FRIRL_WAVE);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = v[i] + t[i];
+    }
+}
+
 __device__ __forceinline__ double block_sum_f64(double v, double *scratch)
 {
     v = wave_sum_f64(v);
@@ -113,6 +129,8 @@ struct Options {
     int lanes_wpe;        // lane groups: waves per SIMD, 0 = by shape                           (FRIRL_HIP_LANES_WPE)
     int rollout_group;    // shared-base roll-out: lanes per environment, 0 = by shape           (FRIRL_HIP_ROLLOUT_GROUP)
     int rollout_slices;   // shared-base roll-out: rule slices, 0 = by shape                     (FRIRL_HIP_ROLLOUT_SLICES)
+    int mirror_server;    // single-agent fused step: 0 = always one launch per step, 1 = resident step server for small rule bases, N > 1 = the same with an idle limit of N ms (FRIRL_HIP_MIRROR_SERVER)
+    int mirror_sync;      // single-agent fused step: 1 = wait with hipStreamSynchronize instead of polling the completion flag (FRIRL_HIP_MIRROR_SYNC)
     int no_many;          // 9..24 actions: 1 = action-parallel waves (sweep_gba_wide) instead of all actions in registers (FRIRL_HIP_NO_MANY)
 };
 const Options &opts();

@@ -587,6 +587,13 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
         }
     }
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+#if FRIRL_GBA_POISON
+    wave_sum_f64_n(sv);                              // the 2 AMAX butterflies in one pass (device_common.h)
+    wave_sum_f64_n(sw);
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+        if (a < A && lane == 0) { s.v[wave][a] = sv[a]; s.w[wave][a] = sw[a]; s.h[wave][a] = FRIRL_HIP_NO_HIT; }
+#else
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {
         if (a < A) {
@@ -595,6 +602,7 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
             if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; s.h[wave][a] = th; }
         }
     }
+#endif
     __syncthreads();
     if ((int)threadIdx.x < A) {
         const int a = threadIdx.x;
@@ -744,6 +752,13 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     qres.vagc = blk_sum<BLOCK>(qv, red);
     qres.ws = blk_sum<BLOCK>(qw, red);
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+#if FRIRL_GBA_POISON
+    wave_sum_f64_n(sv);                              // the 2 AMAX butterflies in one pass (device_common.h)
+    wave_sum_f64_n(sw);
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+        if (a < A && lane == 0) { s.v[wave][a] = sv[a]; s.w[wave][a] = sw[a]; s.h[wave][a] = FRIRL_HIP_NO_HIT; }
+#else
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {
         if (a < A) {
@@ -752,6 +767,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
             if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; s.h[wave][a] = th; }
         }
     }
+#endif
     __syncthreads();
     if ((int)threadIdx.x < A) {
         const int a = threadIdx.x;
@@ -790,7 +806,7 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
 {
     constexpr int NS = NANT - 1;
     constexpr int G = 3;
-    static_assert(AMAX % G == 0, "groups of three actions");
+    static_assert(AMAX % G == 0 && AMAX % 12 == 0, "groups of three actions, reduction passes of twelve");
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FRIRL_WAVE));
     double sv[AMAX], sw[AMAX], av[AMAX];
 #pragma unroll
@@ -866,13 +882,23 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
         qres->ws = blk_sum<BLOCK>(qw, red);
         qres->tracked = false;
     }
+    // the 2 A butterflies in passes of 12 sums (one pass for all of them would need 48 more VGPRs than the sweep has; padded actions
+    // ride along)
 #pragma unroll
-    for (int a = 0; a < AMAX; a++) {
-        if (a < A) {
-            const double tv = wave_sum_f64(sv[a]), tw = wave_sum_f64(sw[a]);
-            if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; }
+    for (int a0 = 0; a0 < AMAX; a0 += 12) {
+        if (a0 < A) {
+            double tv[12], tw[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) { tv[i] = sv[a0 + i]; tw[i] = sw[a0 + i]; }
+            wave_sum_f64_n(tv);
+            wave_sum_f64_n(tw);
+#pragma unroll
+            for (int i = 0; i < 12; i++) { sv[a0 + i] = tv[i]; sw[a0 + i] = tw[i]; }
         }
     }
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+        if (a < A && lane == 0) { s.v[wave][a] = sv[a]; s.w[wave][a] = sw[a]; }
     __syncthreads();
     if ((int)threadIdx.x < A) {
         const int a = threadIdx.x;
