@@ -129,7 +129,6 @@ struct Options {
     int lanes_wpe;        // lane groups: waves per SIMD, 0 = by shape                           (FRIRL_HIP_LANES_WPE)
     int rollout_group;    // shared-base roll-out: lanes per environment, 0 = by shape           (FRIRL_HIP_ROLLOUT_GROUP)
     int rollout_slices;   // shared-base roll-out: rule slices, 0 = by shape                     (FRIRL_HIP_ROLLOUT_SLICES)
-    int mirror_server;    // single-agent fused step: 0 = always one launch per step, 1 = resident step server for small rule bases, N > 1 = the same with an idle limit of N ms (FRIRL_HIP_MIRROR_SERVER)
     int mirror_sync;      // single-agent fused step: 1 = wait with hipStreamSynchronize instead of polling the completion flag (FRIRL_HIP_MIRROR_SYNC)
     int no_many;          // 9..24 actions: 1 = action-parallel waves (sweep_gba_wide) instead of all actions in registers (FRIRL_HIP_NO_MANY)
 };

@@ -27,12 +27,6 @@ struct five_hip_mirror {
     int32_t *h_ipin;
     void *h_out, *d_out;         // pinned + device-mapped result block of the fused step (written by the kernel)
     uint32_t step_seq;           // number of the last fused step (completion flag of the result block)
-    void *h_mb, *d_mb;           // mailbox of the resident step server (mapped, coherent)
-    int srv_running;             // the server kernel is resident on `s`: every other use of the stream quiesces it first
-    int srv_cap;                 // rules its LDS slab holds
-    int srv_A;                   // action bucket it was launched for
-    int srv_refused;             // slab-full hand-back at this rule count: serve again only after the rule base shrank
-    struct five_hip_mirror *next_live;      // list of live mirrors (process-exit quiesce)
     double *h_rconc, *d_rconc;   // pinned + device-mapped copy of the consequents after the step
     double grid_sig;             // checksum of the agent grid last uploaded to d_grid
     int grid_valid;
@@ -54,17 +48,6 @@ int frirl_launch_mirror_step(const frirl_hip_tables *t, const frirl_hip_rulebase
                              const double *cur_q_states, const double *action_ve, const double *action_values, int A, int fus, double *rant_store,
                              void *out_dev, double *rconc_out_dev, uint32_t seq, hipStream_t s);
 size_t frirl_mirror_step_out_bytes();
-// resident step server (sarsa.hip: mirror_server_kernel)
-size_t frirl_mirror_mailbox_bytes();
-size_t frirl_mirror_server_lds(int nant, int U, int A, int cap);
-int frirl_launch_mirror_server(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int A, int cap, double *rant_store,
-                               void *mailbox_dev, void *out_dev, double *rconc_out_dev, uint32_t last_seq, double idle_seconds, hipStream_t s);
-void frirl_mirror_mailbox_post(void *mailbox_host, int nant, const double *q_ant, double reward, const double *cur_q_states, const double *action_ve,
-                               const double *action_values, int A, int fus, uint32_t seq);
-void frirl_mirror_mailbox_reset(void *mailbox_host, uint32_t seq);
-void frirl_mirror_mailbox_quit(void *mailbox_host);
-void frirl_mirror_mailbox_times(const void *mailbox_host, unsigned long long *v);
-int frirl_mirror_mailbox_exited(const void *mailbox_host);
 bool frirl_mirror_step_done(const void *out_host, uint32_t seq);
 void frirl_mirror_step_unpack(const void *out_host, int nant, int A, uint32_t *best, double *actconc, double *cur_q_ant, int32_t *fus, int32_t *status,
                               int32_t *nrules, double *new_rant, double *new_rconc);
@@ -74,29 +57,6 @@ __global__ void bestact_kernel(const double *__restrict__ rb, const int32_t *__r
                                const double *__restrict__ dists, double *__restrict__ conc);
 __global__ void remove_rule_kernel(double *__restrict__ rb, int maxR, int cols, int R, int r);
 }
-
-// ---- resident step server: life cycle ---------------------------------------------------------------------------------------------
-static five_hip_mirror *g_live = nullptr;        // mirrors with a possibly resident server (single-threaded use per mirror; the list is only
-static bool g_atexit = false;                    // walked at process exit)
-
-// Ask a resident server to leave and wait for its write-back.  Called by every entry point that uses the stream or the device state.
-static int mirror_quiesce(five_hip_mirror *m)
-{
-    if (!m->srv_running) return FRIRL_HIP_OK;
-    frirl_mirror_mailbox_quit(m->h_mb);
-    HIPCHK(hipStreamSynchronize(m->s), "step server shutdown");
-    m->srv_running = 0;
-    return FRIRL_HIP_OK;
-}
-static void mirror_quiesce_all()
-{
-    for (five_hip_mirror *m = g_live; m; m = m->next_live) (void)mirror_quiesce(m);
-}
-#define QUIESCE(m)                                  \
-    do {                                            \
-        const int qrc_ = mirror_quiesce(m);         \
-        if (qrc_) return qrc_;                      \
-    } while (0)
 
 extern "C" five_hip_mirror *five_hip_mirror_create(int32_t nant, int32_t U, const double *u, const double *ve, int32_t maxR, int32_t p)
 {
@@ -116,12 +76,10 @@ extern "C" five_hip_mirror *five_hip_mirror_create(int32_t nant, int32_t U, cons
     ok = ok && hipHostMalloc((void **)&m->h_pin, sizeof(double) * PIN_DOUBLES, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&m->h_ipin, 256, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(&m->h_out, frirl_mirror_step_out_bytes(), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&m->d_out, m->h_out, 0) == hipSuccess;
-    ok = ok && hipHostMalloc(&m->h_mb, frirl_mirror_mailbox_bytes(), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&m->d_mb, m->h_mb, 0) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&m->h_rconc, sizeof(double) * m->maxR, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
          hipHostGetDevicePointer((void **)&m->d_rconc, m->h_rconc, 0) == hipSuccess;
     if (ok) {
         memset(m->h_out, 0, frirl_mirror_step_out_bytes());          // completion flag starts at step 0
-        memset(m->h_mb, 0, frirl_mirror_mailbox_bytes());
         ok = hipMemcpyAsync(m->d_u, u, tb, hipMemcpyHostToDevice, m->s) == hipSuccess &&
              hipMemcpyAsync(m->d_ve, ve, tb, hipMemcpyHostToDevice, m->s) == hipSuccess &&
              hipMemsetAsync(m->d_rb, 0, sb, m->s) == hipSuccess && hipMemsetAsync(m->d_nrules, 0, 64, m->s) == hipSuccess &&
@@ -137,30 +95,18 @@ extern "C" five_hip_mirror *five_hip_mirror_create(int32_t nant, int32_t U, cons
     m->t.nant = nant; m->t.U = U; m->t.u = m->d_u; m->t.ve = m->d_ve;
     m->b.E = 1; m->b.maxR = m->maxR; m->b.rb = m->d_rb; m->b.nrules = m->d_nrules; m->b.uidx = nullptr;
     m->R = 0;
-    m->next_live = g_live;
-    g_live = m;
     return m;
 }
 
 extern "C" void five_hip_mirror_destroy(five_hip_mirror *m)
 {
     if (!m) return;
-    (void)mirror_quiesce(m);
-    if (getenv("FRIRL_HIP_MIRROR_TIMES") && m->h_mb) {          // where the served steps spent their time (device wall clock, 10 ns ticks)
-        unsigned long long v[4];
-        frirl_mirror_mailbox_times(m->h_mb, v);
-        if (v[0]) fprintf(stderr, "step server: %llu steps; per step: inputs %.2f us, step %.2f us, results %.2f us (device clock)\n", v[0], v[1] * 0.01 / v[0],
-                          v[2] * 0.01 / v[0], v[3] * 0.01 / v[0]);
-    }
-    for (five_hip_mirror **pp = &g_live; *pp; pp = &(*pp)->next_live)
-        if (*pp == m) { *pp = m->next_live; break; }
     if (m->s) (void)hipStreamSynchronize(m->s);
     (void)hipFree(m->d_u); (void)hipFree(m->d_ve); (void)hipFree(m->d_rb); (void)hipFree(m->d_nrules); (void)hipFree(m->d_buf);
     (void)hipFree(m->d_row); (void)hipFree(m->d_grid); (void)hipFree(m->d_rant); (void)hipFree(m->d_ibuf);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
     if (m->h_ipin) (void)hipHostFree(m->h_ipin);
     if (m->h_out) (void)hipHostFree(m->h_out);
-    if (m->h_mb) (void)hipHostFree(m->h_mb);
     if (m->h_rconc) (void)hipHostFree(m->h_rconc);
     if (m->s) (void)hipStreamDestroy(m->s);
     free(m);
@@ -179,7 +125,6 @@ static int set_nrules(five_hip_mirror *m, int32_t R)
 extern "C" int five_hip_mirror_upload(five_hip_mirror *m, int32_t R, const double *const *veval_rows, const double *rconc)
 {
     if (!m || R < 0 || R > m->maxR || (R && (!veval_rows || !rconc))) { set_error("five_hip_mirror_upload: bad arguments"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     HIPCHK(hipMemsetAsync(m->d_rb, 0, sizeof(double) * (size_t)(m->nant + 1) * m->maxR, m->s), "slab clear");
     for (int k = 0; k < m->nant && R; k++)
         HIPCHK(hipMemcpyAsync(m->d_rb + (size_t)k * m->maxR, veval_rows[k], sizeof(double) * R, hipMemcpyHostToDevice, m->s), "veval upload");
@@ -193,7 +138,6 @@ extern "C" int five_hip_mirror_upload(five_hip_mirror *m, int32_t R, const doubl
 extern "C" int five_hip_mirror_add_rule(five_hip_mirror *m, const double *rant, double rconc)
 {
     if (!m || !rant) { set_error("five_hip_mirror_add_rule: NULL"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     if (m->R >= m->maxR) { set_error("five_hip_mirror_add_rule: rule base full (%d)", m->maxR); return FRIRL_HIP_EINVAL; }
     memcpy(m->h_pin, rant, sizeof(double) * m->nant);
     m->h_pin[m->nant] = rconc;
@@ -208,7 +152,6 @@ extern "C" int five_hip_mirror_add_rule(five_hip_mirror *m, const double *rant, 
 extern "C" int five_hip_mirror_remove_rule(five_hip_mirror *m, uint32_t r)
 {
     if (!m || (int32_t)r >= m->R) { set_error("five_hip_mirror_remove_rule: rule %u out of range", r); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     hipLaunchKernelGGL(frirl::remove_rule_kernel, dim3(m->nant + 1), dim3(256), 0, m->s, m->d_rb, m->maxR, m->nant + 1, m->R, (int)r);
     hipLaunchKernelGGL(frirl::remove_rule_kernel, dim3(m->nant), dim3(256), 0, m->s, m->d_rant, m->maxR, m->nant, m->R, (int)r);
     int rc = check_launch("five_hip_mirror_remove_rule");
@@ -221,7 +164,6 @@ extern "C" int five_hip_mirror_remove_rule(five_hip_mirror *m, uint32_t r)
 extern "C" int five_hip_mirror_set_rconc(five_hip_mirror *m, const double *rconc, int32_t R)
 {
     if (!m || !rconc || R < 0 || R > m->maxR) { set_error("five_hip_mirror_set_rconc: bad arguments"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     if (R) HIPCHK(hipMemcpyAsync(m->d_rb + (size_t)m->nant * m->maxR, rconc, sizeof(double) * R, hipMemcpyHostToDevice, m->s), "rconc upload");
     HIPCHK(hipStreamSynchronize(m->s), "set_rconc sync");
     return FRIRL_HIP_OK;
@@ -230,7 +172,6 @@ extern "C" int five_hip_mirror_set_rconc(five_hip_mirror *m, const double *rconc
 extern "C" int five_hip_mirror_get_rconc(five_hip_mirror *m, double *rconc, int32_t R)
 {
     if (!m || !rconc || R < 0 || R > m->maxR) { set_error("five_hip_mirror_get_rconc: bad arguments"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     if (R) HIPCHK(hipMemcpyAsync(rconc, m->d_rb + (size_t)m->nant * m->maxR, sizeof(double) * R, hipMemcpyDeviceToHost, m->s), "rconc download");
     HIPCHK(hipStreamSynchronize(m->s), "get_rconc sync");
     return FRIRL_HIP_OK;
@@ -246,7 +187,6 @@ static int upload_obs(five_hip_mirror *m, const double *x, int n, int at)
 extern "C" int five_hip_mirror_rule_distance(five_hip_mirror *m, const double *x, double *ruledists, uint32_t *hit)
 {
     if (!m || !x || !hit) { set_error("five_hip_mirror_rule_distance: NULL"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     int rc = upload_obs(m, x, m->nant, 0);
     if (rc) return rc;
     uint32_t *d_hit = reinterpret_cast<uint32_t *>(m->d_ibuf);
@@ -261,7 +201,6 @@ extern "C" int five_hip_mirror_rule_distance(five_hip_mirror *m, const double *x
 extern "C" int five_hip_mirror_vag_concl(five_hip_mirror *m, const double *x, double *conc, uint32_t *hit)
 {
     if (!m || !x || !conc || !hit) { set_error("five_hip_mirror_vag_concl: NULL"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     int rc = upload_obs(m, x, m->nant, 0);
     if (rc) return rc;
     uint32_t *d_hit = reinterpret_cast<uint32_t *>(m->d_ibuf);
@@ -277,7 +216,6 @@ extern "C" int five_hip_mirror_vag_concl(five_hip_mirror *m, const double *x, do
 extern "C" int five_hip_mirror_vag_concl_weight(five_hip_mirror *m, const double *x, double *weights, uint32_t *hit)
 {
     if (!m || !x || !weights || !hit) { set_error("five_hip_mirror_vag_concl_weight: NULL"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     int rc = upload_obs(m, x, m->nant, 0);
     if (rc) return rc;
     uint32_t *d_hit = reinterpret_cast<uint32_t *>(m->d_ibuf);
@@ -295,7 +233,6 @@ extern "C" int five_hip_mirror_vag_concl_weight(five_hip_mirror *m, const double
 extern "C" int five_hip_mirror_bestact(five_hip_mirror *m, const double *ruledists, double *conc)
 {
     if (!m || !ruledists || !conc) { set_error("five_hip_mirror_bestact: NULL"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     if (m->R) HIPCHK(hipMemcpyAsync(m->d_row, ruledists, sizeof(double) * m->R, hipMemcpyHostToDevice, m->s), "ruledists upload");
     int rc = five_hip_bestact(&m->b, m->nant, m->p, m->d_row, m->d_buf + 64, m->s);
     if (rc) return rc;
@@ -309,7 +246,6 @@ extern "C" int five_hip_mirror_get_best_action(five_hip_mirror *m, const double 
                                                double *actconc, uint32_t *best)
 {
     if (!m || !states || !action_ve || !actconc || !best || A < 1 || A > FRIRL_HIP_MAX_ACTIONS) { set_error("five_hip_mirror_get_best_action: bad arguments"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     memcpy(m->h_pin, states, sizeof(double) * (m->nant - 1));
     memcpy(m->h_pin + 32, action_ve, sizeof(double) * A);
     HIPCHK(hipMemcpyAsync(m->d_buf, m->h_pin, sizeof(double) * (32 + A), hipMemcpyHostToDevice, m->s), "gba upload");
@@ -329,7 +265,6 @@ extern "C" int five_hip_mirror_update_sarsa(five_hip_mirror *m, const frirl_hip_
                                             double *rconc)
 {
     if (!m || !agent || !agent->grid_values || !q_ant || !cur_q_ant || !fus || !status) { set_error("five_hip_mirror_update_sarsa: NULL"); return FRIRL_HIP_EINVAL; }
-    QUIESCE(m);
     const int n = m->nant;
     // staging: [0,n) q_ant, [16,16+n) cur_q_ant, [32] reward, [64, 64 + n*MAX_GRID) grid
     memcpy(m->h_pin, q_ant, sizeof(double) * n);
@@ -373,57 +308,6 @@ extern "C" int five_hip_mirror_update_sarsa(five_hip_mirror *m, const frirl_hip_
     return FRIRL_HIP_OK;
 }
 
-// One fused step through the resident server.  Returns 1 = done (results in h_out / h_rconc), 0 = not served (the caller launches the
-// per-step kernel; the server, if any, has left and written the rule base back), < 0 = -(1000 + error code).
-static int server_step(five_hip_mirror *m, const frirl_hip_agent *ag, const double *q_ant, double reward, const double *cur_q_states, const double *action_ve,
-                       const double *action_values, int32_t A, int32_t fus, uint32_t seq)
-{
-    auto fail = [&](int rc) { return -(1000 + rc); };
-    const int so = opts().mirror_server;
-    const int bucket = A <= 4 ? 4 : (A <= 8 ? 8 : 32);
-    bool want = so != 0 && m->nant >= 2 && m->nant <= 9 && A <= FRIRL_HIP_MAX_ACTIONS;
-    int cap = m->maxR < 1024 ? m->maxR : 1024;
-    while (want && cap >= 256 && !frirl_mirror_server_lds(m->nant, m->U, A, cap)) cap -= 256;      // as many rules as fit beside the tables
-    want = want && cap >= 256 && frirl_mirror_server_lds(m->nant, m->U, A, cap) != 0 && m->R < cap;
-    if (m->srv_refused && m->R >= m->srv_refused) want = false;                                      // slab was full at this size
-    if (want && m->srv_running && (m->srv_A != bucket || m->srv_cap != cap)) { const int rc = mirror_quiesce(m); if (rc) return fail(rc); }
-    if (!want) { const int rc = mirror_quiesce(m); return rc ? fail(rc) : 0; }
-    const double idle_s = so > 1 ? so * 1e-3 : 0.2;             // mirror_server = N > 1: idle limit in milliseconds (tests)
-    for (int attempt = 0; attempt < 3; attempt++) {
-        if (!m->srv_running) {
-            frirl_mirror_mailbox_reset(m->h_mb, seq - 1);
-            const int rc = frirl_launch_mirror_server(&m->t, &m->b, ag, A, cap, m->d_rant, m->d_mb, m->d_out, m->d_rconc, seq - 1, idle_s, m->s);
-            if (rc) return fail(rc);
-            m->srv_running = 1; m->srv_cap = cap; m->srv_A = bucket;
-            if (!g_atexit) { g_atexit = true; atexit(mirror_quiesce_all); }
-        }
-        frirl_mirror_mailbox_post(m->h_mb, m->nant, q_ant, reward, cur_q_states, action_ve, action_values, A, fus, seq);
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        int why = 0;
-        for (;;) {
-            if (frirl_mirror_step_done(m->h_out, seq)) return 1;
-            if ((why = frirl_mirror_mailbox_exited(m->h_mb)) != 0) break;
-            __builtin_ia32_pause();
-            if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
-                frirl_mirror_mailbox_quit(m->h_mb);
-                (void)hipStreamSynchronize(m->s);
-                m->srv_running = 0;
-                set_error("five_hip_mirror_greedy_step: the resident step kernel did not answer within 10 s");
-                return fail(FRIRL_HIP_ELAUNCH);
-            }
-        }
-        // the server left (idle limit, or its LDS slab is full): wait for the write-back
-        if (hipStreamSynchronize(m->s) != hipSuccess) { set_error("five_hip_mirror_greedy_step: step server: %s", hipGetErrorString(hipGetLastError())); m->srv_running = 0; return fail(FRIRL_HIP_ELAUNCH); }
-        m->srv_running = 0;
-        if (frirl_mirror_step_done(m->h_out, seq)) return 1;                     // answered just before leaving
-        if (why == 3) { m->srv_refused = m->R > 0 ? m->R : 1; return 0; }         // slab full: the per-step kernel takes over from this step on
-        // idle exit raced with the post: start it again, the command is still in the mailbox
-    }
-    set_error("five_hip_mirror_greedy_step: the resident step kernel keeps leaving");
-    return fail(FRIRL_HIP_ELAUNCH);
-}
-
 extern "C" int five_hip_mirror_greedy_step(five_hip_mirror *m, const frirl_hip_agent *agent, const double *q_ant, double reward,
                                            const double *cur_q_states, const double *action_ve, const double *action_values, int32_t A,
                                            uint32_t *best, double *actconc, double *cur_q_ant, int32_t *fus, int32_t *status, double *new_rant,
@@ -436,7 +320,6 @@ extern "C" int five_hip_mirror_greedy_step(five_hip_mirror *m, const frirl_hip_a
     for (int i = 0; i < n * FRIRL_HIP_MAX_GRID; i++) sig += agent->grid_values[i] * (double)(i + 1);
     for (int k = 0; k < n; k++) sig += 1e6 * agent->grid_len[k] * (k + 1);
     if (!m->grid_valid || sig != m->grid_sig) {
-        QUIESCE(m);                                   // a resident server holds its own copy of the grid
         memcpy(m->h_pin + 64, agent->grid_values, sizeof(double) * n * FRIRL_HIP_MAX_GRID);
         HIPCHK(hipMemcpyAsync(m->d_grid, m->h_pin + 64, sizeof(double) * n * FRIRL_HIP_MAX_GRID, hipMemcpyHostToDevice, m->s), "grid upload");
         m->grid_sig = sig;
@@ -447,18 +330,6 @@ extern "C" int five_hip_mirror_greedy_step(five_hip_mirror *m, const frirl_hip_a
     ag.action_ve = nullptr;
     ag.p = m->p;
     const uint32_t seq = ++m->step_seq;
-    // small rule bases: the resident step server (sarsa.hip: mirror_server_kernel)
-    {
-        const int sr = server_step(m, &ag, q_ant, reward, cur_q_states, action_ve, action_values, A, *fus, seq);
-        if (sr < 0) return -sr - 1000;                 // error (FRIRL_HIP_* codes are negative: encoded below)
-        if (sr == 1) {
-            int32_t nr = 0;
-            frirl_mirror_step_unpack(m->h_out, n, A, best, actconc, cur_q_ant, fus, status, &nr, new_rant, new_rconc);
-            m->R = nr;
-            if (rconc && nr) memcpy(rconc, m->h_rconc, sizeof(double) * nr);
-            return FRIRL_HIP_OK;
-        }
-    }
     int rc = frirl_launch_mirror_step(&m->t, &m->b, &ag, q_ant, reward, cur_q_states, action_ve, action_values, A, *fus, m->d_rant, m->d_out, m->d_rconc, seq, m->s);
     if (rc) return rc;
     // wait for the kernel's completion flag in the mapped result block (a few microseconds); hipStreamSynchronize only as the fallback

@@ -38,7 +38,6 @@ static const OptName k_opts[] = {
     {"rollout_slices", "FRIRL_HIP_ROLLOUT_SLICES", &Options::rollout_slices, 0},
     {"no_many", "FRIRL_HIP_NO_MANY", &Options::no_many, 0},
     {"mirror_sync", "FRIRL_HIP_MIRROR_SYNC", &Options::mirror_sync, 0},
-    {"mirror_server", "FRIRL_HIP_MIRROR_SERVER", &Options::mirror_server, 0},
 };
 static void opts_init()
 {

@@ -455,6 +455,11 @@ __global__ __launch_bounds__(FRIRL_WAVE) void episode_run_kernel(const double *_
 
 // ---- single rule base, one launch per environment step (ANSI-C drop-in path) -------------------------------------------
 // Inputs by value in the kernel arguments, outputs written directly into pinned host memory (no staging copies).
+// (A RESIDENT kernel serving the steps through a mailbox in host-mapped memory -- universes, VE tables, grids and the rule base held in
+//  LDS, inputs polled over PCIe, results released with a flag -- was built and measured in round 2 (git history: commit "single-agent
+//  drop-in step: ... experiment: resident step server"; profiles/r02_single_agent_step_server.txt): 3.6-3.9 us for the PCIe read of
+//  the inputs + 5.4-11 us of LDS-resident work + 1.5 us for the results per step, i.e. no better than this kernel once the host polls
+//  its completion flag -- the environment is the caller's C callback, so every step is a host round trip either way.  Dropped.)
 struct MirrorStepArgs {
     double q_ant[FRIRL_HIP_MAX_NANT];
     double cur_q_states[FRIRL_HIP_MAX_NANT];
@@ -530,142 +535,6 @@ __global__ __launch_bounds__(BLOCK) void mirror_step_kernel(const double *__rest
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&out->seq, in.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// ---- single rule base, RESIDENT step server (ANSI-C drop-in path, small rule bases) ---------------------------------------
-// The one-launch-per-step kernel above costs 10-17 us of GPU time per step at the demos' 100-400 rules -- about twenty DEPENDENT global
-// accesses (tables, columns, reductions through memory) -- plus a launch; the reference's CPU does the whole step in ~18 us.  The
-// environment itself cannot move to the device here (it is the caller's C callback), so the kernel stays resident instead: one
-// workgroup keeps the universes, VE tables, grids and the rule-base slab in LDS and serves steps through a mailbox in host-mapped,
-// coherent memory: the host writes the step's inputs and bumps `cmd_seq`; thread 0 polls it (one PCIe read per poll), the workgroup
-// runs the fused step out of LDS, writes the results + the consequent column to the mapped result block and releases `out->seq`, which
-// the host polls in its own memory.  Per step: two PCIe latencies + a few microseconds of LDS-resident work.
-// The server leaves -- writing the slab back and raising `exited` -- when the host asks (`quit`: every other entry point that touches
-// the mirror does, and so does the library at process exit), when no command arrives for `idle_ticks` of the 100 MHz wall clock (the
-// host relaunches it on demand), or when the LDS slab is full (the host continues with the per-step kernel).  Every wave takes the same
-// exit decision (broadcast through LDS), so the grid always drains.
-struct MirrorMailbox {           // host memory, mapped + coherent
-    MirrorStepArgs args;         // host -> device, complete before cmd_seq is released
-    uint32_t cmd_seq;            // number of the step the host wants (> the last completed one)
-    uint32_t quit;               // 1: leave now
-    uint32_t exited;             // device -> host: 1 after the write-back, just before the server returns
-    uint32_t exit_reason;        // 1 quit, 2 idle, 3 slab full (the pending step was NOT executed)
-    // where a served step spends its time, in 10 ns ticks of the device wall clock, summed over the server's life (written at exit)
-    unsigned long long steps, t_args, t_body, t_out;
-};
-
-template <int NANT, int AMAX, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void mirror_server_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U, double *__restrict__ rb,
-                                                               int32_t *__restrict__ nrules, int maxR, int cap, const frirl_hip_agent ag,
-                                                               double *__restrict__ rant_store, MirrorMailbox *mb, MirrorStepOut *out,
-                                                               double *__restrict__ rconc_out, uint32_t last_seq, long long idle_ticks)
-{
-    constexpr int NS = NANT - 1;
-    extern __shared__ double dyn_s[];                  // [NANT][U] universes, [NANT][U] vague environments, [(NANT+1)][cap] rule base
-    __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
-    __shared__ StepShared sh;
-    __shared__ BlockRed<BLOCK> red;
-    __shared__ GbaScratch<AMAX, BLOCK> gs;
-    __shared__ double avalues_s[FRIRL_HIP_MAX_ACTIONS];
-    __shared__ int32_t nrules_s, fus_s, cmd_s, A_s;
-    __shared__ uint32_t seq_s;
-    double *u_s = dyn_s, *ve_s = dyn_s + NANT * U, *slab_s = dyn_s + 2 * NANT * U;
-    const int R0 = nrules[0];
-    for (int i = threadIdx.x; i < NANT * U; i += BLOCK) { u_s[i] = u[i]; ve_s[i] = ve[i]; }
-    for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += BLOCK) grid_s[i] = ag.grid_values[i];
-    for (int k = 0; k <= NANT; k++)
-        for (int r = threadIdx.x; r < cap; r += BLOCK) slab_s[k * cap + r] = (r < R0) ? rb[(size_t)k * maxR + r] : 0.0;
-    if (threadIdx.x == 0) nrules_s = R0;
-    frirl_hip_agent agl = ag;
-    agl.grid_values = grid_s;
-    const ColsLds cols{slab_s, cap};
-    double *qcol = slab_s + (size_t)NANT * cap;
-    const int p = ag.p > 0 ? ag.p : NANT;
-    volatile MirrorMailbox *vmb = mb;
-    int reason = 0;
-    unsigned long long n_steps = 0, t_args = 0, t_body = 0, t_out = 0;       // thread 0
-    __syncthreads();
-    for (;;) {
-        if (threadIdx.x == 0) {                        // wait for the next step, the quit request or the idle limit
-            const long long t0 = wall_clock64();
-            int cmd = 0;
-            uint32_t sq = last_seq;
-            for (;;) {
-                sq = __hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (sq != last_seq) { cmd = 1; break; }
-                if (__hip_atomic_load(&mb->quit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { cmd = 2; break; }
-                if (wall_clock64() - t0 > idle_ticks) { cmd = 3; break; }
-            }
-            cmd_s = cmd; seq_s = sq;
-        }
-        __syncthreads();
-        if (cmd_s != 1) { reason = cmd_s == 2 ? 1 : 2; break; }
-        const long long c0 = wall_clock64();
-        // the step's inputs: one PCIe round trip, every value by its own lane
-        if (threadIdx.x < NANT) sh.q_ant[threadIdx.x] = vmb->args.q_ant[threadIdx.x];
-        else if (threadIdx.x >= 32 && threadIdx.x < 32 + NS) sh.cur_q_ant[threadIdx.x - 32] = vmb->args.cur_q_states[threadIdx.x - 32];
-        else if (threadIdx.x >= 64 && threadIdx.x < 64 + (AMAX < FRIRL_HIP_MAX_ACTIONS ? AMAX : FRIRL_HIP_MAX_ACTIONS)) gs.ave[threadIdx.x - 64] = vmb->args.action_ve[threadIdx.x - 64];
-        else if (threadIdx.x >= 128 && threadIdx.x < 128 + FRIRL_HIP_MAX_ACTIONS) avalues_s[threadIdx.x - 128] = vmb->args.action_values[threadIdx.x - 128];
-        else if (threadIdx.x == 192) sh.reward = vmb->args.reward;
-        else if (threadIdx.x == 193) fus_s = vmb->args.fus;
-        else if (threadIdx.x == 194) A_s = vmb->args.A;
-        __syncthreads();
-        const long long c1 = wall_clock64();
-        const int A = A_s;
-        if (threadIdx.x < NANT) sh.ve1[threadIdx.x] = observe_ve(u_s, ve_s, U, threadIdx.x, sh.q_ant[threadIdx.x]);
-        if (threadIdx.x >= 64 && threadIdx.x < 64 + NS) sh.ve2[threadIdx.x - 64] = observe_ve(u_s, ve_s, U, threadIdx.x - 64, sh.cur_q_ant[threadIdx.x - 64]);
-        __syncthreads();
-        double q[NS], q1[NANT];
-#pragma unroll
-        for (int k = 0; k < NS; k++) q[k] = sh.ve2[k];
-#pragma unroll
-        for (int k = 0; k < NANT; k++) q1[k] = sh.ve1[k];
-        QResult rn;
-        int ap;
-        if constexpr (AMAX > 8) ap = sweep_gba_wide<NANT, 8, AMAX, BLOCK, true>(cols, qcol, nrules_s, q, q1, p, A, gs, red, &rn);     // see mirror_step_kernel
-        else ap = sweep_gba_q<NANT, AMAX, BLOCK>(cols, qcol, nrules_s, q, q1, p, A, gs, red, rn);
-        if (threadIdx.x == 0) {
-            sh.cur_q_ant[NS] = avalues_s[ap];
-            sh.ve2[NS] = gs.ave[ap];
-        }
-        __syncthreads();
-        const double qp = gs.actconc[ap];
-        const int R_before = nrules_s;
-        const int st = update_sarsa_block<NANT, BLOCK>(cols, u_s, ve_s, U, slab_s, cap, &nrules_s, agl, sh, sh.reward, true, qp, &fus_s, nullptr, red, &rn, nullptr, p, nullptr);
-        __syncthreads();
-        if (st == FRIRL_HIP_UPD_FULL && cap < maxR) { reason = 3; break; }       // LDS slab full, the rule base is not: hand the (unexecuted) step back
-        const int R = nrules_s;
-        const long long c2 = wall_clock64();
-        if (st == FRIRL_HIP_UPD_INSERTED && threadIdx.x < NANT) {
-            rant_store[(size_t)threadIdx.x * maxR + R_before] = sh.rant[threadIdx.x];
-            out->new_rant[threadIdx.x] = sh.rant[threadIdx.x];
-        }
-        if ((int)threadIdx.x < A) out->actconc[threadIdx.x] = gs.actconc[threadIdx.x];
-        if (threadIdx.x >= 64 && threadIdx.x < 64 + NANT) out->cur_q_ant[threadIdx.x - 64] = sh.cur_q_ant[threadIdx.x - 64];
-        for (int r = threadIdx.x; r < R; r += BLOCK) rconc_out[r] = qcol[r];
-        if (threadIdx.x == 0) {
-            if (st == FRIRL_HIP_UPD_INSERTED) out->new_rconc = qcol[R_before];
-            out->best = ap; out->fus = fus_s; out->status = st; out->nrules = R;
-        }
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(&out->seq, seq_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        last_seq = seq_s;
-        const long long c3 = wall_clock64();
-        n_steps++; t_args += (unsigned long long)(c1 - c0); t_body += (unsigned long long)(c2 - c1); t_out += (unsigned long long)(c3 - c2);
-    }
-    // write back: grown / updated slab and the rule count; then tell the host
-    const int R1 = nrules_s;
-    for (int k = 0; k <= NANT; k++)
-        for (int r = threadIdx.x; r < R1; r += BLOCK) rb[(size_t)k * maxR + r] = slab_s[k * cap + r];
-    if (threadIdx.x == 0) nrules[0] = R1;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        vmb->steps = vmb->steps + n_steps; vmb->t_args = vmb->t_args + t_args; vmb->t_body = vmb->t_body + t_body; vmb->t_out = vmb->t_out + t_out;
-        vmb->exit_reason = (uint32_t)reason;
-        __hip_atomic_store(&mb->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // frirl_sequential_run's construct-loop bookkeeping (reference src/frirl/frirl_sequential_run.c:68-72,83-148),
@@ -996,78 +865,6 @@ int frirl_launch_mirror_step(const frirl_hip_tables *t, const frirl_hip_rulebase
         default: set_error("five_hip_mirror_greedy_step: nant=%d outside 2..9", t->nant); return FRIRL_HIP_EINVAL;
     }
     return check_launch("five_hip_mirror_greedy_step");
-}
-
-// ---- resident step server: host-side helpers for mirror.hip -------------------------------------------------------------------
-size_t frirl_mirror_mailbox_bytes() { return sizeof(frirl::MirrorMailbox); }
-
-// LDS the server needs for `cap` rules; 0 when the shape is not served (tables too large, too many actions)
-size_t frirl_mirror_server_lds(int nant, int U, int A, int cap)
-{
-    if (nant < 2 || nant > 9 || A < 1 || A > FRIRL_HIP_MAX_ACTIONS) return 0;
-    const size_t b = sizeof(double) * ((size_t)2 * nant * U + (size_t)(nant + 1) * cap);
-    return b <= 140 * 1024 ? b : 0;                   // 160 KiB per CU minus the kernel's static LDS
-}
-
-int frirl_launch_mirror_server(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int A, int cap, double *rant_store,
-                               void *mailbox_dev, void *out_dev, double *rconc_out_dev, uint32_t last_seq, double idle_seconds, hipStream_t s)
-{
-    const size_t dyn = frirl_mirror_server_lds(t->nant, t->U, A, cap);
-    if (!dyn) { set_error("five_hip_mirror_greedy_step: shape not served by the resident kernel"); return FRIRL_HIP_EINVAL; }
-    frirl::MirrorMailbox *mb = static_cast<frirl::MirrorMailbox *>(mailbox_dev);
-    frirl::MirrorStepOut *out = static_cast<frirl::MirrorStepOut *>(out_dev);
-    const long long ticks = (long long)(idle_seconds * 1.0e8);          // wall_clock64: 100 MHz
-    hipError_t e1 = hipSuccess;
-#define SRV(N, AM)                                                                                                                            \
-    do {                                                                                                                                      \
-        auto k = frirl::mirror_server_kernel<N, AM, 256>;                                                                                    \
-        if (dyn > 48 * 1024) e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-        if (e1 == hipSuccess)                                                                                                                 \
-            hipLaunchKernelGGL(k, dim3(1), dim3(256), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, cap, *ag, rant_store, mb, out, rconc_out_dev, last_seq, ticks); \
-    } while (0)
-    switch (t->nant) {
-#define M(N)                                                        \
-    case N:                                                         \
-        if (A <= 4) SRV(N, 4); else if (A <= 8) SRV(N, 8); else SRV(N, 32); \
-        break;
-        FRIRL_Q_NANT_CASES(M)
-#undef M
-        default: set_error("five_hip_mirror_greedy_step: nant=%d outside 2..9", t->nant); return FRIRL_HIP_EINVAL;
-    }
-#undef SRV
-    if (e1 != hipSuccess) { set_error("five_hip_mirror_greedy_step: hipFuncSetAttribute(%zu B of LDS): %s", dyn, hipGetErrorString(e1)); return FRIRL_HIP_ELAUNCH; }
-    return check_launch("five_hip_mirror_greedy_step(server)");
-}
-
-// host side of the mailbox (mapped memory): post one step / ask the server to leave / read its state
-void frirl_mirror_mailbox_post(void *mailbox_host, int nant, const double *q_ant, double reward, const double *cur_q_states, const double *action_ve,
-                               const double *action_values, int A, int fus, uint32_t seq)
-{
-    frirl::MirrorMailbox *mb = static_cast<frirl::MirrorMailbox *>(mailbox_host);
-    memcpy(mb->args.q_ant, q_ant, sizeof(double) * nant);
-    memcpy(mb->args.cur_q_states, cur_q_states, sizeof(double) * (nant - 1));
-    memcpy(mb->args.action_ve, action_ve, sizeof(double) * A);
-    memcpy(mb->args.action_values, action_values, sizeof(double) * A);
-    mb->args.reward = reward; mb->args.fus = fus; mb->args.A = A; mb->args.seq = seq;
-    __atomic_store_n(&mb->cmd_seq, seq, __ATOMIC_RELEASE);
-}
-void frirl_mirror_mailbox_reset(void *mailbox_host, uint32_t seq)
-{
-    frirl::MirrorMailbox *mb = static_cast<frirl::MirrorMailbox *>(mailbox_host);
-    mb->quit = 0; mb->exit_reason = 0; mb->cmd_seq = seq;
-    __atomic_store_n(&mb->exited, 0u, __ATOMIC_RELEASE);
-}
-void frirl_mirror_mailbox_times(const void *mailbox_host, unsigned long long *v)
-{
-    const frirl::MirrorMailbox *mb = static_cast<const frirl::MirrorMailbox *>(mailbox_host);
-    v[0] = mb->steps; v[1] = mb->t_args; v[2] = mb->t_body; v[3] = mb->t_out;
-}
-void frirl_mirror_mailbox_quit(void *mailbox_host) { __atomic_store_n(&static_cast<frirl::MirrorMailbox *>(mailbox_host)->quit, 1u, __ATOMIC_RELEASE); }
-int frirl_mirror_mailbox_exited(const void *mailbox_host)          // 0 = running, else the exit reason (1 quit, 2 idle, 3 slab full)
-{
-    const frirl::MirrorMailbox *mb = static_cast<const frirl::MirrorMailbox *>(mailbox_host);
-    if (__atomic_load_n(&mb->exited, __ATOMIC_ACQUIRE) == 0u) return 0;
-    return mb->exit_reason ? (int)mb->exit_reason : 1;
 }
 
 size_t frirl_mirror_step_out_bytes() { return sizeof(frirl::MirrorStepOut); }
