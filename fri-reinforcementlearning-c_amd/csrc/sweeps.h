@@ -513,7 +513,7 @@ __device__ __forceinline__ bool wave_no_state_hit(bool second, double s0, double
 // rsq(0) poison the two sums of exactly that action, and only note the hit: d^2 = (av - va)^2 + s == 0 needs a zero state part s -- rare
 // -- and then means av == va.  The side path scans the actions and takes an LDS atomic min (first hit = lowest rule index).  No per-action
 // hit register, compare, branch or select.  The odd tail (r + 1 == R) gets a huge state part instead of a branch: its weight
-// (1e300)^(-P/2) underflows to exactly 0 and adds +0 to both sums.
+// (1e300)^(-P/2) is 0 (P >= 3: underflow) or at most 1e-150 -- added to sums that are >= ~0.1 (d <= sqrt(nant)) it changes no bit.
 #ifndef FRIRL_STEP_PREFETCH
 #define FRIRL_STEP_PREFETCH 1
 #endif
