@@ -250,17 +250,25 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 }
 
 // frirl_episode(): one step of the loop (reference src/frirl/frirl_episode.c:86-185), fused.
-// register budget of the step kernel: 6 waves per SIMD (<= 80 VGPRs) for the 3-antecedent / <= 4-action shape, 4 (<= 128)
-// for the others -- without the bound the 5-antecedent, many-action variants sit just above 128 and lose a wave
+// register budget of the step kernel: 8 waves per SIMD (<= 64 VGPRs) for the 3-antecedent / <= 4-action shape -- it needs 63 now that
+// the observations sit in SGPRs and exact hits need no registers, and 8192 one-wave environments are then resident at once instead of
+// 6144 + a ragged second round --, 4 (<= 128) for the others: without the bound the 5-antecedent, many-action variants sit just above
+// 128 and lose a wave
 // (the action-parallel kernel, amax > 8: 3 waves = 168 VGPRs -- its branch-free conclusion terms keep more chains in flight, and with
 // cartpole's 40 KB of LDS tables only three workgroups fit a CU anyway)
 #ifndef FRIRL_STEP_WAVES_N3
-#define FRIRL_STEP_WAVES_N3 6
+#define FRIRL_STEP_WAVES_N3 8
 #endif
 constexpr int step_min_waves(int nant, int amax) { return (nant <= 3 && amax <= 4) ? FRIRL_STEP_WAVES_N3 : (amax > 8 ? 3 : 4); }
 
 // TRACK: the candidates of update_rules' write-back are collected during the fused sweep (sweeps.h: SpreadCand) -- for LARGE rule
 // bases, where the second sweep it saves is a second pass over HBM; small slabs are re-read from L2 and the plain form is faster.
+#ifdef FRIRL_STEP_TIMING
+// experiment build only (tools/build_variant.sh timing -DFRIRL_STEP_TIMING): when each workgroup of the step kernel started, finished its
+// fused sweep and left, in 10 ns ticks of the device wall clock -- read back with frirl_hip_debug_step_timing
+__device__ long long g_step_timing[4 * 65536];
+#endif
+
 template <int NANT, int AMAX, int BLOCK, bool IDX, bool PN, bool TRACK>
 __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_step_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                               double *__restrict__ rb, uint16_t *__restrict__ uidx, int32_t *__restrict__ nrules,
@@ -268,6 +276,9 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
 {
     constexpr int NS = NANT - 1;
     const int e = blockIdx.x;
+#ifdef FRIRL_STEP_TIMING
+    const long long tm0 = wall_clock64();
+#endif
     if (ev.done[e]) {
         if (threadIdx.x == 0 && ev.status) ev.status[e] = FRIRL_HIP_UPD_INACTIVE;
         return;
@@ -309,6 +320,9 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     if constexpr (AMAX == 24) ap = sweep_gba_many<NANT, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn);
     else if constexpr (AMAX > 8) ap = sweep_gba_wide<NANT, 8, AMAX, BLOCK, true, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn, ag.weight_significant, cand_s);
     else ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
+#ifdef FRIRL_STEP_TIMING
+    const long long tm1 = wall_clock64();
+#endif
     if (threadIdx.x == 0) {
         const int chosen = e_greedy(ag, ap, (uint32_t)e, ev.episode ? (uint32_t)ev.episode[e] : 0u, (uint32_t)ev.ep_steps[e] + 1u);
         gs.best = chosen;
@@ -330,9 +344,20 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
         ev.ep_reward[e] = ev.ep_reward[e] + sh.reward;                                                // :107
         if (sh.success == 1 || steps >= ag.max_steps) ev.done[e] = 1;                                 // :183, :86
         if (ev.status) ev.status[e] = st;
+#ifdef FRIRL_STEP_TIMING
+        if (e < 65536) { g_step_timing[4 * e] = tm0; g_step_timing[4 * e + 1] = tm1; g_step_timing[4 * e + 2] = wall_clock64(); g_step_timing[4 * e + 3] = st; }
+#endif
     }
 }
 
+#ifdef FRIRL_STEP_TIMING
+}  // namespace frirl
+extern "C" int frirl_hip_debug_step_timing(long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(frirl::g_step_timing), sizeof(long long) * 4 * (size_t)n) == hipSuccess ? 0 : -3;
+}
+namespace frirl {
+#endif
 
 // Persistent episode kernel for SMALL rule bases (the demos' real learning regime: <= 367 rules).
 // One wave owns one environment for up to `nsteps` consecutive steps: the rule base slab, the universes / VE

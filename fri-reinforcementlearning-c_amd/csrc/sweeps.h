@@ -628,11 +628,17 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
 // instead of twice that.  Per-lane accumulation order and the reduction tree are those of the two separate
 // sweeps, so every result is bit-identical to running them one after the other.
 template <int NANT, int AMAX, int BLOCK, bool TRACK = false, class COLS, class POW>
-__device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs)[NANT - 1 > 0 ? NANT - 1 : 1],
-                           const double (&q1)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres, double track_thr = 0.0,
+__device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs_in)[NANT - 1 > 0 ? NANT - 1 : 1],
+                           const double (&q1_in)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres, double track_thr = 0.0,
                            SpreadCand *slot = nullptr)
 {
     constexpr int NS = NANT - 1;
+    // the two observations are wave-uniform: in scalar registers they cost the sweep no VGPRs (a VOP3 reads one scalar operand)
+    double qs[NS > 0 ? NS : 1], q1[NANT];
+#pragma unroll
+    for (int k = 0; k < (NS > 0 ? NS : 1); k++) qs[k] = wave_uniform(qs_in[k]);
+#pragma unroll
+    for (int k = 0; k < NANT; k++) q1[k] = wave_uniform(q1_in[k]);
     if (TRACK) slot[threadIdx.x].clear();          // `slot` = the workgroup's slot array, one entry per lane
     qres.tracked = TRACK;
     track_thr = wave_uniform(track_thr * SPREAD_PREFILTER_SLACK);
