@@ -250,14 +250,14 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 }
 
 // frirl_episode(): one step of the loop (reference src/frirl/frirl_episode.c:86-185), fused.
-// register budget of the step kernel: 8 waves per SIMD (<= 64 VGPRs) for the 3-antecedent / <= 4-action shape -- it needs 63 now that
-// the observations sit in SGPRs and exact hits need no registers, and 8192 one-wave environments are then resident at once instead of
-// 6144 + a ragged second round --, 4 (<= 128) for the others: without the bound the 5-antecedent, many-action variants sit just above
-// 128 and lose a wave
+// register budget of the step kernel: 6 waves per SIMD (<= 80 VGPRs) for the 3-antecedent / <= 4-action shape (it needs ~64 now that
+// the observations sit in SGPRs and exact hits need no registers; 8 waves -- all 8192 one-wave environments of the 8192 x 8192 shape
+// resident at once -- measured the same 0.24 ms: the kernel is issue-bound, profiles/r02_step_timeline.txt), 4 (<= 128) for the
+// others: without the bound the 5-antecedent, many-action variants sit just above 128 and lose a wave
 // (the action-parallel kernel, amax > 8: 3 waves = 168 VGPRs -- its branch-free conclusion terms keep more chains in flight, and with
 // cartpole's 40 KB of LDS tables only three workgroups fit a CU anyway)
 #ifndef FRIRL_STEP_WAVES_N3
-#define FRIRL_STEP_WAVES_N3 8
+#define FRIRL_STEP_WAVES_N3 6
 #endif
 constexpr int step_min_waves(int nant, int amax) { return (nant <= 3 && amax <= 4) ? FRIRL_STEP_WAVES_N3 : (amax > 8 ? 3 : 4); }
 

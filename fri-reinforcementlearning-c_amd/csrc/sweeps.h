@@ -359,6 +359,32 @@ struct QResult {
     bool tracked;   // the lanes' SpreadCand slots hold the candidates of this sweep
 };
 
+// One PAIR of rules (r, r + 1) of a Q-value sweep with squared distances a0, a1 (a1 = NO_RULE_STATE_PART when rule r + 1 does not
+// exist): the first exact hit is noted in a side path taken only when some lane of the wave has one; the Shepard terms are added
+// unconditionally -- an exact hit poisons the two sums (rsq(0)), and a conclusion with an exact hit is the hit rule's consequent, its sums
+// are not read (FIVEVagConcl.c:89-93; QResult::vagc / ws are valid when hit == NO_HIT).  No branch and no register copies around the
+// FP64 chains of the common case.
+#ifndef FRIRL_GBA_POISON
+#define FRIRL_GBA_POISON 1
+#endif
+static constexpr double NO_RULE_STATE_PART = 1.0e300;
+template <class POW>
+__device__ __forceinline__ void q_pair(double a0, double a1, const double2 &c, unsigned r, POW pk, unsigned &best, double &sv, double &sw, double &tw0,
+                                       double &tw1)
+{
+    if (__builtin_amdgcn_ballot_w64(a0 == 0.0 || a1 == 0.0) != 0ull) {
+        if (a0 == 0.0) best = min(best, r);
+        if (a1 == 0.0) best = min(best, r + 1u);
+    }
+    const double w0 = shepard_w(a0, pk), w1 = shepard_w(a1, pk);
+    sv = __fma_rn(w0, c.x, sv);
+    sw = sw + w0;
+    sv = __fma_rn(w1, c.y, sv);
+    sw = sw + w1;
+    tw0 = w0;
+    tw1 = w1;
+}
+
 // FIVE_vag_concl's sweep (reference src/five/FIVEVagConcl.c:64-351 live path): distances, first
 // exact hit, Shepard sums wi = 1/d^p, vagc = sum wi*Q, ws = sum wi (:224-235).  All threads return
 // the same QResult.
@@ -373,6 +399,7 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
     if (TRACK) slot[threadIdx.x].clear();          // `slot` = the workgroup's slot array, one entry per lane
     track_thr = wave_uniform(track_thr * SPREAD_PREFILTER_SLACK);
     double T = 0.0;
+    const auto pk = pin_pow(p);
     // tracked form: wave-uniform trip count (spread_track is a wave-level operation); lanes past R idle through their last turn
     const int r_lim = TRACK ? wave_uniform_limit(R) : R;
     for (int r = 2 * (int)threadIdx.x; r < r_lim; r += 2 * BLOCK) {
@@ -381,6 +408,11 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
             double a0, a1;
             sq_dist2<NANT>(cols, r, q, a0, a1);
             const double2 c = load_col2(qcol + r);
+#if FRIRL_GBA_POISON
+            if (r + 1 >= R) a1 = NO_RULE_STATE_PART;
+            q_pair(a0, a1, c, (unsigned)r, pk, best, sv, sw, tw0, tw1);
+        }
+#else
             if (a0 == 0.0) best = min(best, (unsigned)r);
             else {
                 const double wi = shepard_w(a0, p);
@@ -398,6 +430,7 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
                 }
             }
         }
+#endif
         if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, sw);
     }
     res.hit = blk_min<BLOCK>(best, red);
@@ -518,10 +551,6 @@ __device__ __forceinline__ bool wave_no_state_hit(bool second, double s0, double
 #define FRIRL_STEP_PREFETCH 1
 #endif
 static constexpr int STEP_PREFETCH = FRIRL_STEP_PREFETCH;      // rule pairs requested ahead per lane in sweep_gba_q
-#ifndef FRIRL_GBA_POISON
-#define FRIRL_GBA_POISON 1
-#endif
-static constexpr double NO_RULE_STATE_PART = 1.0e300;
 __device__ __forceinline__ void note_state_hits(unsigned *hit_s, const double *ave_s, int A, double s0, double s1, const double2 &va, unsigned r)
 {
     if (__builtin_amdgcn_ballot_w64(s0 == 0.0 || s1 == 0.0) != 0ull) {
@@ -703,12 +732,17 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                 a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
+#if FRIRL_GBA_POISON
+            if (!second) a1 = NO_RULE_STATE_PART;
+            q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
+#else
             if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
             else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; tw0 = wi; }
             if (second) {
                 if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
                 else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; tw1 = wi; }
             }
+#endif
         }
         if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);
         if (live) {
@@ -854,12 +888,9 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
                 d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                 a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
-            if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = shepard_w(a0, pk); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; }
-            if (second) {
-                if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = shepard_w(a1, pk); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; }
-            }
+            if (!second) a1 = NO_RULE_STATE_PART;
+            double tw0, tw1;
+            q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
         }
         double s0, s1;
         {
@@ -1013,12 +1044,17 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                     d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                     a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
                 }
+#if FRIRL_GBA_POISON
+                if (!second) a1 = NO_RULE_STATE_PART;
+                q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
+#else
                 if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
                 else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; tw0 = wi; }
                 if (second) {
                     if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
                     else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; tw1 = wi; }
                 }
+#endif
             }
             if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);
         }
