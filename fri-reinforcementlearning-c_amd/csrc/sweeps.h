@@ -214,6 +214,7 @@ __device__ __forceinline__ double2 load_col2_shared(const double *__restrict__ p
 // universe indices (frirl_hip_rulebases.uidx) and reads the VE values from an LDS copy of the tables: the same
 // doubles (rb[k][r] == ve[k][uidx[k][r]] exactly), a quarter of the antecedent bytes.
 struct ColsF64 {
+    static constexpr bool GLOBAL_Q = true;     // the consequent column lies in global memory (QColBuf applies)
     const double *base;   // rb slab of the environment
     int maxR;
     __device__ __forceinline__ double2 pair(int k, int r) const { return load_col2(base + (size_t)k * maxR + r); }
@@ -223,7 +224,33 @@ struct ColsF64 {
     __device__ __forceinline__ double2 decode(int, const raw_t &w) const { return w; }
 };
 
+// Streams of the hot sweeps as raw BUFFER loads: one descriptor per slab (4 SGPRs, built once), the column offset k * maxR in a scalar
+// register, ONE per-lane byte offset shared by all columns -- against one 64-bit pointer per column, advanced with two vector
+// instructions each per iteration.  The step kernels are bound by vector issue; this takes ~6 of their ~200 instructions per pair of rules.
+#ifndef FRIRL_BUF_LOADS
+#define FRIRL_BUF_LOADS 1
+#endif
+static constexpr int BUFFER_RSRC_DWORD3 = 0x00020000;      // gfx9 family: raw buffer, 32-bit data format
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_buffer(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)0x7fffffff, BUFFER_RSRC_DWORD3);
+}
+// consequent column as a buffer: 16-byte non-temporal loads of (q[r], q[r + 1])
+struct QColBuf {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ explicit QColBuf(const double *qcol) : rs(raw_buffer(qcol)) {}
+    __device__ __forceinline__ double2 load2(int r) const
+    {
+        const auto w = __builtin_amdgcn_raw_buffer_load_b128(rs, 8 * r, 0, 2);
+        double2 v;
+        v.x = __longlong_as_double((long long)(((unsigned long long)w[1] << 32) | w[0]));
+        v.y = __longlong_as_double((long long)(((unsigned long long)w[3] << 32) | w[2]));
+        return v;
+    }
+};
+
 struct ColsIdx {
+    static constexpr bool GLOBAL_Q = true;
     const uint16_t *idx;  // uidx slab of the environment
     const double *tab;    // LDS [nant][U]
     int maxR, U;
@@ -236,7 +263,14 @@ struct ColsIdx {
         return v;
     }
     using raw_t = uint32_t;
-    __device__ __forceinline__ raw_t raw(int k, int r) const { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(idx + (size_t)k * maxR + r)); }
+    __device__ __forceinline__ raw_t raw(int k, int r) const
+    {
+#if FRIRL_BUF_LOADS
+        return __builtin_amdgcn_raw_buffer_load_b32(raw_buffer(idx), 2 * r, 2 * k * maxR, 2);       // aux 2: non-temporal
+#else
+        return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(idx + (size_t)k * maxR + r));
+#endif
+    }
     __device__ __forceinline__ raw_t raw_shared(int k, int r) const { return *reinterpret_cast<const uint32_t *>(idx + (size_t)k * maxR + r); }
     __device__ __forceinline__ double2 decode(int k, raw_t w) const
     {
@@ -249,6 +283,7 @@ struct ColsIdx {
 
 // rule base resident in LDS (persistent episode kernel): plain 16-byte reads of the workgroup's own slab copy
 struct ColsLds {
+    static constexpr bool GLOBAL_Q = false;
     const double *base;   // LDS [nant+1][cap]
     int cap;
     __device__ __forceinline__ double2 pair(int k, int r) const { return *reinterpret_cast<const double2 *>(base + (size_t)k * cap + r); }
@@ -690,6 +725,11 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     // PD stages in flight (FRIRL_STEP_PREFETCH): with one stage a 256-thread workgroup has 9 KB requested ahead, ~45 KB per CU --
     // about what 8 TB/s x 1.5 us of loaded HBM latency needs chip-wide, nothing to spare
     constexpr int PD = STEP_PREFETCH;
+    const QColBuf qb(qcol);
+    auto ldq = [&](int r) {
+        if constexpr (COLS::GLOBAL_Q && FRIRL_BUF_LOADS) return qb.load2(r);
+        else return load_col2(qcol + r);
+    };
     typename COLS::raw_t nraw[PD][NANT];
     double2 nc[PD];
 #pragma unroll
@@ -699,7 +739,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
         if (r0 < R) {
 #pragma unroll
             for (int k = 0; k < NANT; k++) nraw[u][k] = cols.raw(k, r0);
-            nc[u] = load_col2(qcol + r0);
+            nc[u] = ldq(r0);
         }
     }
     double T = 0.0;
@@ -720,7 +760,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
             if (r + PD * 2 * BLOCK < R) {
 #pragma unroll
                 for (int k = 0; k < NANT; k++) sraw[k] = cols.raw(k, r + PD * 2 * BLOCK);
-                sc = load_col2(qcol + r + PD * 2 * BLOCK);
+                sc = ldq(r + PD * 2 * BLOCK);
             }
 #pragma unroll
             for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
@@ -856,6 +896,11 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
     unsigned qbest = FRIRL_HIP_NO_HIT;
     double qv = 0.0, qw = 0.0;
     const auto pk = pin_pow(p);
+    const QColBuf qb(qcol);
+    auto ldq = [&](int r) {
+        if constexpr (COLS::GLOBAL_Q && FRIRL_BUF_LOADS) return qb.load2(r);
+        else return load_col2(qcol + r);
+    };
     typename COLS::raw_t nraw[NANT];
     double2 nc = {0.0, 0.0};
     {
@@ -863,7 +908,7 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
         if (r0 < R) {
 #pragma unroll
             for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r0);
-            nc = load_col2(qcol + r0);
+            nc = ldq(r0);
         }
     }
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
@@ -876,7 +921,7 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
         if (r + 2 * BLOCK < R) {
 #pragma unroll
             for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * BLOCK);
-            nc = load_col2(qcol + r + 2 * BLOCK);
+            nc = ldq(r + 2 * BLOCK);
         }
 #pragma unroll
         for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
