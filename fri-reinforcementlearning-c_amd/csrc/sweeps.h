@@ -769,17 +769,16 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
         double2 c = {0.0, 0.0};
         double tw0 = 0.0, tw1 = 0.0;
         if (live) {
-            typename COLS::raw_t raw[NANT];
-#pragma unroll
-            for (int k = 0; k < NANT; k++) raw[k] = sraw[k];
+            // decode FIRST, then refill the stage: the index words die in the decode, so the loads of the next pair can land in the
+            // same registers (requested before the decode they cost one register copy per column and iteration)
             c = sc;
+#pragma unroll
+            for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, sraw[k]);
             if (r + PD * 2 * BLOCK < R) {
 #pragma unroll
                 for (int k = 0; k < NANT; k++) sraw[k] = cols.raw(k, r + PD * 2 * BLOCK);
                 sc = ldq(r + PD * 2 * BLOCK);
             }
-#pragma unroll
-            for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
             // (1) Q(s,a): full distance to the pending antecedents
             double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
             double a0 = d0 * d0, a1 = d1 * d1;
@@ -930,17 +929,14 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         const bool second = (r + 1 < R);
         double2 v[NANT];
-        typename COLS::raw_t raw[NANT];
-#pragma unroll
-        for (int k = 0; k < NANT; k++) raw[k] = nraw[k];
         const double2 c = nc;
+#pragma unroll
+        for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, nraw[k]);        // decode first, then refill (see sweep_gba_q)
         if (r + 2 * BLOCK < R) {
 #pragma unroll
             for (int k = 0; k < NANT; k++) nraw[k] = cols.raw(k, r + 2 * BLOCK);
             nc = ldq(r + 2 * BLOCK);
         }
-#pragma unroll
-        for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, raw[k]);
         if (WITH_Q) {
             double d0 = q1[0] - v[0].x, d1 = q1[0] - v[0].y;
             double a0 = d0 * d0, a1 = d1 * d1;
