@@ -164,7 +164,10 @@ struct StoreIdx {
     __device__ __forceinline__ void decode(const Rec &x, double (&c)[NANT + 1]) const
     {
 #pragma unroll
-        for (int k = 0; k < NANT; k++) c[k] = ve_s[k * U + ((word(x.w, k >> 1) >> (16 * (k & 1))) & 0xffffu)];
+        for (int k = 0; k < NANT; k++) {           // one v_mad_u32_u16 per antecedent (sweeps.h: lds_table_entry)
+            if (k & 1) c[k] = lds_table_entry<1>(ve_s + k * U, word(x.w, k >> 1));
+            else c[k] = lds_table_entry<0>(ve_s + k * U, word(x.w, k >> 1));
+        }
         c[NANT] = x.q;
     }
     __device__ __forceinline__ double *qptr(int r) const { return Tq + (unsigned)(r * EPW); }

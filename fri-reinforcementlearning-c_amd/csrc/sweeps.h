@@ -274,6 +274,21 @@ __device__ __forceinline__ double2 lds_table_pair(const double *tab_k, uint32_t 
     return v;
 }
 
+// one entry: table value at the low (HALF = 0) or high (HALF = 1) 16-bit index of a packed word
+template <int HALF>
+__device__ __forceinline__ double lds_table_entry(const double *tab_k, uint32_t w)
+{
+#if FRIRL_DECODE_MAD
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_cdouble *)tab_k;
+    uint32_t a;
+    if constexpr (HALF == 0) asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[0,0,0,0]" : "=v"(a) : "v"(w), "s"(base));
+    else asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "s"(base));
+    return *(lds_cdouble *)(uintptr_t)a;
+#else
+    return tab_k[HALF ? (w >> 16) : (w & 0xFFFFu)];
+#endif
+}
+
 struct ColsIdx {
     static constexpr bool GLOBAL_Q = true;
     const uint16_t *idx;  // uidx slab of the environment
