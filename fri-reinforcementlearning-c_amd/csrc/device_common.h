@@ -41,6 +41,31 @@ __device__ __forceinline__ double observe_ve(const double *__restrict__ u, const
     return ve[(size_t)k * U + snap_index(uni, U, xk, universe_div(uni, U))];
 }
 
+// Two 16-bit universe indices packed in one word -> the LDS byte addresses of their table entries, ONE instruction each:
+// v_mad_u32_u16 takes the low or the high half of the word (op_sel), multiplies by 8 and adds the table's LDS address (a scalar
+// operand).  The compiler's own sequence is extract (v_and / v_bfe) + v_lshl_add: 4 instead of 2 vector instructions per pair of
+// antecedents, ~10 % of the acrobot step's instructions (tools/exp/mad_u16.hip checks the encoding on the device).
+#ifndef FRIRL_DECODE_MAD
+#define FRIRL_DECODE_MAD 1
+#endif
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ double2 lds_table_pair(const double *tab_k, uint32_t w)
+{
+    double2 v;
+#if FRIRL_DECODE_MAD
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_cdouble *)tab_k;
+    uint32_t a0, a1;
+    asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(w), "s"(base));
+    asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(w), "s"(base));
+    v.x = *(lds_cdouble *)(uintptr_t)a0;
+    v.y = *(lds_cdouble *)(uintptr_t)a1;
+#else
+    v.x = tab_k[w & 0xFFFFu];
+    v.y = tab_k[w >> 16];
+#endif
+    return v;
+}
+
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
 #pragma unroll

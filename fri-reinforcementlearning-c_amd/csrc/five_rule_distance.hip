@@ -122,12 +122,14 @@ __global__ __launch_bounds__(FRIRL_BLOCK) void rule_distance_kernel(
 template <int NANT>
 __device__ __forceinline__ double2 idx_pair_distance(const uint32_t (&w)[NANT], const double (&q)[NANT], const double *__restrict__ tab_s, int U)
 {
-    double d0 = q[0] - tab_s[w[0] & 0xFFFFu], d1 = q[0] - tab_s[w[0] >> 16];
+    double2 t = lds_table_pair(tab_s, w[0]);                  // one v_mad_u32_u16 per index (device_common.h)
+    double d0 = q[0] - t.x, d1 = q[0] - t.y;
     double a0 = d0 * d0, a1 = d1 * d1;
 #pragma unroll
     for (int k = 1; k < NANT; k++) {
-        d0 = q[k] - tab_s[k * U + (w[k] & 0xFFFFu)];
-        d1 = q[k] - tab_s[k * U + (w[k] >> 16)];
+        t = lds_table_pair(tab_s + k * U, w[k]);
+        d0 = q[k] - t.x;
+        d1 = q[k] - t.y;
         const double s0 = d0 * d0, s1 = d1 * d1;
         a0 = a0 + s0;
         a1 = a1 + s1;
