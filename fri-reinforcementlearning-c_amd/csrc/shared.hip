@@ -50,6 +50,7 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
     double bv = -__builtin_inf();
     bi = abeg;
     hit0 = FRIRL_HIP_NO_HIT;
+    const auto pk = pin_pow(p);            // series coefficients of the Shepard weight in registers (sweeps.h)
     // actions in chunks of AMAX accumulators (A = 21: three passes over the L2-resident rule base keep the kernel at
     // ~90 VGPRs instead of 254)
     // `nchunks` is uniform over the workgroup (the tile staging below has barriers); a lane with fewer actions idles
@@ -80,6 +81,10 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
 #pragma unroll
                     for (int k = 1; k < ND; k++) { const double d = q[k] - tl.col[k * SH_TILE + r]; s = __fma_rn(d, d, s); }
                     const double cq = tl.col[NANT * SH_TILE + r];
+                    // a removed rule gets a huge squared distance once (its weight vanishes: the sums keep the bits of the compacted
+                    // rule base); an exact hit is noted with a select and poisons the sums of its own conclusion, which are then not
+                    // read (sweeps.h: q_pair) -- no select around the weight
+                    if (EXCL) s = valid ? s : NO_RULE_STATE_PART;
                     if (GBA) {
                         const double va = tl.col[NS * SH_TILE + r];
 #pragma unroll
@@ -87,19 +92,17 @@ __device__ __forceinline__ void shared_sweep(SharedTile<NANT> &tl, const double 
                             if (a < nacc) {
                                 const double e = tl.ave[a0 + a] - va;
                                 const double d2 = __fma_rn(e, e, s);
-                                const bool z = d2 == 0.0;
-                                const double wi = (z || !valid) ? 0.0 : shepard_w(d2, p);      // an exact hit adds +0.0
+                                const double wi = shepard_w(d2, pk);
                                 sv[a] = __fma_rn(wi, cq, sv[a]);
                                 sw[a] = sw[a] + wi;
-                                sh[a] = (z && valid && sh[a] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[a];
+                                sh[a] = (d2 == 0.0 && sh[a] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[a];
                             }
                         }
                     } else {
-                        const bool z = s == 0.0;
-                        const double wi = (z || !valid) ? 0.0 : shepard_w(s, p);
+                        const double wi = shepard_w(s, pk);
                         sv[0] = __fma_rn(wi, cq, sv[0]);
                         sw[0] = sw[0] + wi;
-                        sh[0] = (z && valid && sh[0] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[0];
+                        sh[0] = (s == 0.0 && sh[0] == FRIRL_HIP_NO_HIT) ? (unsigned)(r0 + r) : sh[0];
                     }
                 }
             }

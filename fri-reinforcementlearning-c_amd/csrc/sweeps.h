@@ -151,6 +151,7 @@ __device__ __forceinline__ double shepard_w(double s, PowCP<P> k)
 // run-time power with the p = 3 / 5 cases unrolled (low-occupancy kernels)
 struct PowU { int p; };
 __device__ __forceinline__ double shepard_w(double s, PowU r) { return inv_dist_pow<true>(s, r.p); }
+__device__ __forceinline__ PowU pin_pow(PowU p) { return p; }
 
 template <bool PN, int N>
 struct PowSel { static __device__ __forceinline__ int make(int p) { return p; } };
