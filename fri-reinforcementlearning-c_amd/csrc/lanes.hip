@@ -227,13 +227,18 @@ template <int NANT, class STORE, class POW>
 __device__ __forceinline__ LaneQ lane_sweep_q(const STORE &st, int R, const double (&q)[NANT], POW p)
 {
     LaneQ o{0.0, 0.0, FRIRL_HIP_NO_HIT};
+    const auto pk = pin_pow(p);
     for_rules<true, NANT>(st, 0, 1, R, [&](int r, const double (&c)[NANT + 1]) {
         const double d0 = q[0] - c[0];
         double s = d0 * d0;
 #pragma unroll
         for (int k = 1; k < NANT; k++) { const double d = q[k] - c[k]; s = __fma_rn(d, d, s); }
-        if (s == 0.0) { if (o.hit == FRIRL_HIP_NO_HIT) o.hit = (unsigned)r; }
-        else { const double wi = shepard_w(s, p); o.v = __fma_rn(wi, c[NANT], o.v); o.w = o.w + wi; }
+        // an exact hit is noted with a select and poisons the two sums, which the caller ignores then (FIVEVagConcl.c:89-93): no
+        // divergent branch around the weight
+        o.hit = (s == 0.0 && o.hit == FRIRL_HIP_NO_HIT) ? (unsigned)r : o.hit;
+        const double wi = shepard_w(s, pk);
+        o.v = __fma_rn(wi, c[NANT], o.v);
+        o.w = o.w + wi;
     });
     return o;
 }
@@ -289,6 +294,7 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
     using POW = typename std::conditional<PN, PowC<NANT>, PowU>::type;
     POW p;
     if constexpr (!PN) p.p = ag.p > 0 ? ag.p : NANT;
+    const auto pk = pin_pow(p);                        // series coefficients of the Shepard weight in registers (sweeps.h)
     const bool has_q = (sub == G - 1);
 
     double states[NS], q_ant[NANT], total = 0.0;
@@ -346,8 +352,12 @@ __global__ __launch_bounds__(LN_BLOCK, WPE) void episode_run_lanes_kernel(const 
                     if (i < nacc) {
                         const double ea = apt[i] - va;
                         const double d2 = __fma_rn(ea, ea, s);
-                        if (d2 == 0.0) { if (hit[i] == FRIRL_HIP_NO_HIT) hit[i] = (unsigned)r; }
-                        else { const double wi = shepard_w(d2, p); sv[i] = __fma_rn(wi, cq, sv[i]); sw[i] = sw[i] + wi; }
+                        // exact hit: noted with a select, its conclusion's sums are poisoned and not read (the conclusion is the
+                        // hit rule's consequent, FIVEVagConcl_FRIRL_BestAct.c:89-93)
+                        hit[i] = (d2 == 0.0 && hit[i] == FRIRL_HIP_NO_HIT) ? (unsigned)r : hit[i];
+                        const double wi = shepard_w(d2, pk);
+                        sv[i] = __fma_rn(wi, cq, sv[i]);
+                        sw[i] = sw[i] + wi;
                     }
                 }
             });
