@@ -73,9 +73,6 @@ __device__ __forceinline__ double shepard_w(double s, int p) { return inv_dist_p
 // and y0^2 is shared between e and the power: 7 FP64 instructions after the rsq for P = 5 (y2, e, y4, y5, c, c e, fma) instead of
 // 9 (6 instead of 7 for P = 3), same 1e-16 accuracy (tools/exp/shepard_prec.hip).  v_rsq_f64 itself issues in ~3.4 FP64 slots
 // (tools/exp/valu_cost.hip); the f32 detour (cvt, v_rsq_f32, cvt) costs the same.
-#ifndef FRIRL_SHEPARD_SERIES
-#define FRIRL_SHEPARD_SERIES 1
-#endif
 template <int P>
 __device__ __forceinline__ double shepard_series(double s, double a, double a2)
 {
@@ -103,21 +100,8 @@ __device__ __forceinline__ double shepard_series(double s, double a, double a2)
 template <int P>
 __device__ __forceinline__ double shepard_w(double s, PowC<P>)
 {
-#if FRIRL_SHEPARD_SERIES
     constexpr double a = 0.5 * P, a2 = 0.5 * a * (a + 1.0);
     return shepard_series<P>(s, a, a2);
-#else
-    const double y = __builtin_amdgcn_rsq(s);
-    const double t = s * y;
-    const double e = __fma_rn(-t, y, 1.0);
-    const double c = __fma_rn(0.375, e, 0.5);
-    const double ce = c * e;
-    const double yr = __fma_rn(y, ce, y);
-    double w = yr;
-#pragma unroll
-    for (int i = 1; i < P; i++) w = w * yr;
-    return w;
-#endif
 }
 
 // The same with the two series coefficients held in registers for the whole sweep (a: VGPR pair, a2: SGPR pair -- a VOP3 takes one
@@ -131,21 +115,15 @@ __device__ __forceinline__ PowCP<P> pin_pow(PowC<P>)
     PowCP<P> r;
     r.a = 0.5 * P;
     r.a2 = 0.5 * (0.5 * P) * (0.5 * P + 1.0);
-#if FRIRL_SHEPARD_SERIES
     asm volatile("" : "+v"(r.a));
     asm volatile("" : "+s"(r.a2));
-#endif
     return r;
 }
 __device__ __forceinline__ int pin_pow(int p) { return p; }
 template <int P>
 __device__ __forceinline__ double shepard_w(double s, PowCP<P> k)
 {
-#if FRIRL_SHEPARD_SERIES
     return shepard_series<P>(s, k.a, k.a2);
-#else
-    return shepard_w(s, PowC<P>());
-#endif
 }
 
 // run-time power with the p = 3 / 5 cases unrolled (low-occupancy kernels)
@@ -406,9 +384,6 @@ struct QResult {
 // unconditionally -- an exact hit poisons the two sums (rsq(0)), and a conclusion with an exact hit is the hit rule's consequent, its sums
 // are not read (FIVEVagConcl.c:89-93; QResult::vagc / ws are valid when hit == NO_HIT).  No branch and no register copies around the
 // FP64 chains of the common case.
-#ifndef FRIRL_GBA_POISON
-#define FRIRL_GBA_POISON 1
-#endif
 static constexpr double NO_RULE_STATE_PART = 1.0e300;
 template <class POW>
 __device__ __forceinline__ void q_pair(double a0, double a1, const double2 &c, unsigned r, POW pk, unsigned &best, double &sv, double &sw, double &tw0,
@@ -450,29 +425,9 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
             double a0, a1;
             sq_dist2<NANT>(cols, r, q, a0, a1);
             const double2 c = load_col2(qcol + r);
-#if FRIRL_GBA_POISON
             if (r + 1 >= R) a1 = NO_RULE_STATE_PART;
             q_pair(a0, a1, c, (unsigned)r, pk, best, sv, sw, tw0, tw1);
         }
-#else
-            if (a0 == 0.0) best = min(best, (unsigned)r);
-            else {
-                const double wi = shepard_w(a0, p);
-                sv = __fma_rn(wi, c.x, sv);
-                sw = sw + wi;
-                tw0 = wi;
-            }
-            if (r + 1 < R) {
-                if (a1 == 0.0) best = min(best, (unsigned)(r + 1));
-                else {
-                    const double wi = shepard_w(a1, p);
-                    sv = __fma_rn(wi, c.y, sv);
-                    sw = sw + wi;
-                    tw1 = wi;
-                }
-            }
-        }
-#endif
         if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, sw);
     }
     res.hit = blk_min<BLOCK>(best, red);
@@ -550,20 +505,17 @@ struct GbaScratch {
     static constexpr int WAVES = BLOCK / FRIRL_WAVE;
     double v[WAVES][AMAX];
     double w[WAVES][AMAX];
-    unsigned h[WAVES][AMAX];
-    unsigned hit[AMAX];         // sweep_gba_many: first exact hit per action (atomic min)
+    unsigned hit[AMAX];         // first exact hit per action, recorded by note_state_hits (atomic min)
     double actconc[AMAX];
     double ave[AMAX];
     int best;
 };
 
-// One action against a PAIR of rules whose state parts s0, s1 are both non-zero: no exact hit is possible (d^2 >= s > 0), so the
-// conclusion terms need neither compares nor branches.  The action-parallel sweep takes this path whenever no lane of the wave holds
-// a rule with a zero state part or an odd tail (wave-uniform test, once per pair of rules instead of twice per action): per conclusion
-// it removes a v_cmp and the ~6 scalar / exec-mask instructions of the two branches (cartpole's 21-action step: 1.05e9 vector + 3.6e8
-// scalar wave-instructions per step before; 2.54 -> 2.41 ms per 4096 environments).  Same operations in the same order as the general
-// form => bit-identical sums.  Not used in sweep_gba / sweep_gba_q: their kernels run at the 80 / 128-VGPR budgets and the second
-// loop body spills the hot loop (mountaincar step 0.25 -> 0.75 ms), and the 5-antecedent / 3-action step is HBM-bound anyway.
+// One action against a PAIR of rules, Shepard terms only (no hit handling): the conclusion terms of every greedy sweep.  sweep_gba,
+// sweep_gba_q and sweep_gba_many record exact hits outside the loop (note_state_hits below) and let a hit poison the sums of its own
+// action; sweep_gba_wide (one action group per wave, hits in registers) takes this body on the wave-uniform fast path -- no lane holds a
+// rule with a zero state part or an odd tail, so no hit is possible (d^2 >= s > 0) -- and a branchy body otherwise (cartpole's 21-action
+// step with it: 2.54 -> 2.41 ms per 4096 environments).  Same operations in the same order in every form => bit-identical sums.
 #ifndef FRIRL_GBA_FASTPATH
 #define FRIRL_GBA_FASTPATH 1
 #endif
@@ -610,77 +562,35 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
 {
     constexpr int NS = NANT - 1;
     double sv[AMAX], sw[AMAX], av[AMAX];
-    unsigned sh[AMAX];
 #pragma unroll
-    for (int a = 0; a < AMAX; a++) {
-        sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT;
-        av[a] = FRIRL_GBA_POISON ? wave_uniform(s.ave[a < A ? a : 0]) : ((a < A) ? s.ave[a] : 0.0);      // poison form: in SGPRs
-    }
-#if FRIRL_GBA_POISON
+    for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; av[a] = wave_uniform(s.ave[a < A ? a : 0]); }      // action values in SGPRs
     if ((int)threadIdx.x < AMAX) s.hit[threadIdx.x] = FRIRL_HIP_NO_HIT;
     __syncthreads();
     const auto pk = pin_pow(p);
-#endif
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double s0 = 0.0, s1 = 0.0;
         if (NS > 0) sq_dist2<(NS > 0 ? NS : 1)>(cols, r, qs, s0, s1);
         const double2 va = cols.pair(NS, r);
         const double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
-#if FRIRL_GBA_POISON
         if (!second) s1 = NO_RULE_STATE_PART;
         note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
 #pragma unroll
         for (int a = 0; a < AMAX; a++)
             if (a < A) concl_pair_nohit(av[a], va, s0, s1, c, pk, sv[a], sw[a]);
-        continue;
-#endif
-#pragma unroll
-        for (int a = 0; a < AMAX; a++) {
-            if (a < A) {
-                const double e0 = av[a] - va.x, e1 = av[a] - va.y;
-                const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);        // squared distances (K5 without the sqrt)
-                if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
-                else {
-                    const double wi = shepard_w(d0, p);
-                    sv[a] = __fma_rn(wi, c.x, sv[a]);
-                    sw[a] = sw[a] + wi;
-                }
-                if (second) {
-                    if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
-                    else {
-                        const double wi = shepard_w(d1, p);
-                        sv[a] = __fma_rn(wi, c.y, sv[a]);
-                        sw[a] = sw[a] + wi;
-                    }
-                }
-            }
-        }
     }
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
-#if FRIRL_GBA_POISON
     wave_sum_f64_n(sv);                              // the 2 AMAX butterflies in one pass (device_common.h)
     wave_sum_f64_n(sw);
 #pragma unroll
     for (int a = 0; a < AMAX; a++)
-        if (a < A && lane == 0) { s.v[wave][a] = sv[a]; s.w[wave][a] = sw[a]; s.h[wave][a] = FRIRL_HIP_NO_HIT; }
-#else
-#pragma unroll
-    for (int a = 0; a < AMAX; a++) {
-        if (a < A) {
-            const double tv = wave_sum_f64(sv[a]), tw = wave_sum_f64(sw[a]);
-            const unsigned th = wave_min_u32(sh[a]);
-            if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; s.h[wave][a] = th; }
-        }
-    }
-#endif
+        if (a < A && lane == 0) { s.v[wave][a] = sv[a]; s.w[wave][a] = sw[a]; }
     __syncthreads();
     if ((int)threadIdx.x < A) {
         const int a = threadIdx.x;
         double tv = s.v[0][a], tw = s.w[0][a];
-        unsigned th = s.h[0][a];
-        for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; th = min(th, s.h[w][a]); }
-        if (FRIRL_GBA_POISON) th = s.hit[a];
+        for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; }
+        const unsigned th = s.hit[a];                   // first exact hit of this action (note_state_hits), or NO_HIT
         s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
     }
     __syncthreads();
@@ -714,17 +624,11 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     qres.tracked = TRACK;
     track_thr = wave_uniform(track_thr * SPREAD_PREFILTER_SLACK);
     double sv[AMAX], sw[AMAX], av[AMAX];
-    unsigned sh[AMAX];
 #pragma unroll
-    for (int a = 0; a < AMAX; a++) {
-        sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT;
-        av[a] = FRIRL_GBA_POISON ? wave_uniform(s.ave[a < A ? a : 0]) : ((a < A) ? s.ave[a] : 0.0);      // poison form: in SGPRs
-    }
-#if FRIRL_GBA_POISON
+    for (int a = 0; a < AMAX; a++) { sv[a] = 0.0; sw[a] = 0.0; av[a] = wave_uniform(s.ave[a < A ? a : 0]); }      // action values in SGPRs
     if ((int)threadIdx.x < AMAX) s.hit[threadIdx.x] = FRIRL_HIP_NO_HIT;
     __syncthreads();
     const auto pk = pin_pow(p);
-#endif
     unsigned qbest = FRIRL_HIP_NO_HIT;
     double qv = 0.0, qw = 0.0;
     // software prefetch: the loads of the NEXT pair of rules are issued before the ~100 FP64 instructions of the current
@@ -778,17 +682,8 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                 a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
-#if FRIRL_GBA_POISON
             if (!second) a1 = NO_RULE_STATE_PART;
             q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
-#else
-            if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-            else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; tw0 = wi; }
-            if (second) {
-                if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; tw1 = wi; }
-            }
-#endif
         }
         if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);
         if (live) {
@@ -804,27 +699,11 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 }
             }
             const double2 va = v[NS];
-#if FRIRL_GBA_POISON
             if (!second) s1 = NO_RULE_STATE_PART;
             note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
 #pragma unroll
             for (int a = 0; a < AMAX; a++)
                 if (a < A) concl_pair_nohit(av[a], va, s0, s1, c, pk, sv[a], sw[a]);
-#else
-#pragma unroll
-            for (int a = 0; a < AMAX; a++) {
-                if (a < A) {
-                    const double e0 = av[a] - va.x, e1 = av[a] - va.y;
-                    const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);        // squared distances
-                    if (d0 == 0.0) sh[a] = min(sh[a], (unsigned)r);
-                    else { const double wi = shepard_w(d0, p); sv[a] = __fma_rn(wi, c.x, sv[a]); sw[a] = sw[a] + wi; }
-                    if (second) {
-                        if (d1 == 0.0) sh[a] = min(sh[a], (unsigned)(r + 1));
-                        else { const double wi = shepard_w(d1, p); sv[a] = __fma_rn(wi, c.y, sv[a]); sw[a] = sw[a] + wi; }
-                    }
-                }
-            }
-#endif
         }
     };
     for (int r = 2 * (int)threadIdx.x; r < r_lim; r += PD * 2 * BLOCK) {
@@ -838,29 +717,17 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
     qres.vagc = blk_sum<BLOCK>(qv, red);
     qres.ws = blk_sum<BLOCK>(qw, red);
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
-#if FRIRL_GBA_POISON
     wave_sum_f64_n(sv);                              // the 2 AMAX butterflies in one pass (device_common.h)
     wave_sum_f64_n(sw);
 #pragma unroll
     for (int a = 0; a < AMAX; a++)
-        if (a < A && lane == 0) { s.v[wave][a] = sv[a]; s.w[wave][a] = sw[a]; s.h[wave][a] = FRIRL_HIP_NO_HIT; }
-#else
-#pragma unroll
-    for (int a = 0; a < AMAX; a++) {
-        if (a < A) {
-            const double tv = wave_sum_f64(sv[a]), tw = wave_sum_f64(sw[a]);
-            const unsigned th = wave_min_u32(sh[a]);
-            if (lane == 0) { s.v[wave][a] = tv; s.w[wave][a] = tw; s.h[wave][a] = th; }
-        }
-    }
-#endif
+        if (a < A && lane == 0) { s.v[wave][a] = sv[a]; s.w[wave][a] = sw[a]; }
     __syncthreads();
     if ((int)threadIdx.x < A) {
         const int a = threadIdx.x;
         double tv = s.v[0][a], tw = s.w[0][a];
-        unsigned th = s.h[0][a];
-        for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; th = min(th, s.h[w][a]); }
-        if (FRIRL_GBA_POISON) th = s.hit[a];
+        for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; }
+        const unsigned th = s.hit[a];                   // first exact hit of this action (note_state_hits), or NO_HIT
         s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
     }
     __syncthreads();
@@ -1092,17 +959,8 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                     d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                     a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
                 }
-#if FRIRL_GBA_POISON
                 if (!second) a1 = NO_RULE_STATE_PART;
                 q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
-#else
-                if (a0 == 0.0) qbest = min(qbest, (unsigned)r);
-                else { const double wi = shepard_w(a0, p); qv = __fma_rn(wi, c.x, qv); qw = qw + wi; tw0 = wi; }
-                if (second) {
-                    if (a1 == 0.0) qbest = min(qbest, (unsigned)(r + 1));
-                    else { const double wi = shepard_w(a1, p); qv = __fma_rn(wi, c.y, qv); qw = qw + wi; tw1 = wi; }
-                }
-#endif
             }
             if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);
         }
