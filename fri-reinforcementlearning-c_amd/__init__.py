@@ -106,6 +106,11 @@ SIGNATURES = {
     "frirl_hip_lanes_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frirl_hip_episode_run_lanes": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_int32,
                                               C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frirl_hip_rollout_resident_rules": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "frirl_hip_learn_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "frirl_hip_learn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "frirl_hip_learn_run": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
+                                      C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "five_hip_add_rule": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "frirl_hip_update_sarsa": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p,
@@ -575,6 +580,55 @@ def train(problem, agent, envs, max_episodes=1000, check_every=50, on_episode=No
         warnings.warn(f"frirl_amd.train: {conv.full_envs} of {problem.E} rule bases reached their capacity of {problem.maxR} rules: "
                       "appends were refused (FRIRL_HIP_UPD_FULL) and those TD updates dropped", RuntimeWarning)
     return conv
+
+
+def learn_supported(problem, agent):
+    """True when frirl_hip_learn_run (the persistent construct loop) covers this shape."""
+    return problem.uidx is not None and bool(lib().frirl_hip_learn_supported(problem.nant, problem.U, agent.A, agent.desc.p, agent.desc.env_kind))
+
+
+class LearnRun:
+    """Result of train_persistent: the Convergence object plus per-agent totals (device tensors)."""
+
+    def __init__(self, conv, steps_total, work, launches):
+        self.conv, self.steps_total, self.work, self.launches = conv, steps_total, work, launches
+
+
+def train_persistent(problem, agent, envs, max_episodes=1000, budget=4096, on_chunk=None, stream=None):
+    """The construct loop of frirl_sequential_run for E agents through frirl_hip_learn_run: every agent runs its episodes
+    back to back on the device; after each launch (<= `budget` steps per agent) the agents that are still learning are
+    compacted and launched again until none is left.  on_chunk(launch index, live agent ids, conv) is called after every
+    launch (the place for the per-chunk reward statistics all-reduce).  Returns a LearnRun."""
+    import torch
+    dev_ = problem.rb.device
+    conv = Convergence(problem, dev_)
+    envs.done.fill_(1)                                   # fresh agents: every one starts its first episode
+    steps_total = torch.zeros((problem.E,), dtype=torch.int64, device=dev_)
+    work = torch.zeros((problem.E, 2), dtype=torch.int64, device=dev_)
+    need = lib().frirl_hip_learn_workspace_bytes(problem.nant, problem.E, problem.maxR, agent.A)
+    ws = getattr(problem, "_learn_ws", None)
+    if ws is None or ws.numel() * 8 < need:
+        ws = torch.empty(((need + 7) // 8,), dtype=torch.float64, device=dev_)
+        problem._learn_ws = ws
+    live = None
+    nlive = problem.E
+    launches = 0
+    while nlive > 0:
+        check(lib().frirl_hip_learn_run(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), C.byref(conv.desc),
+                                        _ptr(live) if live is not None else None, nlive, budget, max_episodes, _ptr(work), _ptr(steps_total),
+                                        _ptr(ws), ws.numel() * 8, _stream(stream)), "frirl_hip_learn_run")
+        launches += 1
+        conv.full |= (envs.status == UPD_FULL)
+        if on_chunk is not None:
+            on_chunk(launches, live, conv)
+        still = (conv.converged == 0) & (conv.episodes < max_episodes - 1)
+        live = still.nonzero().flatten().to(torch.int32).contiguous()      # one host round trip per launch: the number of live agents
+        nlive = int(live.numel())
+    if conv.full_envs:
+        import warnings
+        warnings.warn(f"frirl_amd.train_persistent: {conv.full_envs} of {problem.E} rule bases reached their capacity of {problem.maxR} rules: "
+                      "appends were refused (FRIRL_HIP_UPD_FULL) and those TD updates dropped", RuntimeWarning)
+    return LearnRun(conv, steps_total, work, launches)
 
 
 def demo_describe(env):

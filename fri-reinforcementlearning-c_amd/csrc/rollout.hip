@@ -1,0 +1,459 @@
+// rollout.hip -- frirl_test_run's greedy episode (reference src/frirl/frirl_test_run.c:66-70 -> frirl_episode.c:28-194 with
+// reduction_state == 1) for Q environments on ONE small read-only rule base: the RESIDENT form of frirl_hip_rollout_shared.
+//
+// What limits a roll-out launch is not the arithmetic but the episode lengths: on the acrobot demo the mean episode is 82
+// steps, 2 % take more than 160 and a few per ten thousand never succeed and run to max_steps = 1000.  With one lane per
+// environment and the whole batch resident (shared.hip: rollout_shared_kernel) a launch lasts as long as its longest episode
+// and most lanes idle most of the time.  Here instead:
+//   * the whole rule base lives in LDS (<= ~1200 rules of 5 antecedents), staged once per workgroup: no barrier and no
+//     re-staging per step, every wave runs at its own pace;
+//   * a GROUP of H consecutive lanes owns one environment: lane h evaluates the rules r = h (mod H) for ALL actions (state
+//     part of the squared distance once per rule, A accumulator pairs per lane), the H partial sums are combined by a
+//     butterfly inside the group -- the arithmetic of one step is split H ways without recomputing anything but the
+//     environment's own dynamics;
+//   * groups are fed from an in-order queue (one atomic per wave and refill): a group whose episode ends takes the next
+//     environment at once, so the chip works on min(Q, lanes / H) environments at a time and the launch ends when the queue
+//     is empty, not when the slowest lane of every wave is done;
+//   * an episode that has used `cap` steps in a throughput phase (H = 4 / 16) is PARKED (state, reward so far, pending action)
+//     and finished by a later launch that gives it a whole wave (H = 64: per-step latency ~R/64 rules): the stragglers' serial
+//     chain runs at the latency form's speed instead of holding a throughput wave.  The follow-up launches choose themselves by
+//     the parked count they find on the device (no host round trip).
+// Sums: each lane adds its rules in index order, the H partials are added in butterfly order; every phase of one call runs a
+// different H, so an environment's Shepard sums change their rounding (not their value, <= 1e-13) when it is parked; WHICH
+// environments are parked depends only on their own trajectory and the static cap: results are deterministic.
+#include "sweeps.h"
+#include "envs.h"
+#include <type_traits>
+
+namespace frirl {
+
+constexpr int RR_BLOCK = 256;
+
+struct RolloutCtl {            // device control block, zeroed before the first phase
+    unsigned next[4];          // queue head of each phase launch
+    unsigned parked;           // environments parked by the throughput phase
+    unsigned too_big;          // 1: the rule base does not fit the LDS image -> the tiled kernel (shared.hip) runs instead
+    unsigned pad[2];
+};
+
+struct RolloutPark {           // environments parked by the throughput phase (SoA, capacity Q)
+    int32_t *env;
+    double *states;            // [Q][NS]
+    double *total;
+    int32_t *steps;
+    int32_t *act;              // index of the pending action
+};
+
+struct RolloutPhase {
+    int from_parked;           // 0: items are the environment ids 0..Q-1 (fresh episodes); 1: items are parked records
+    unsigned lo, hi;           // from_parked: run only if lo < parked <= hi
+    int cap;                   // steps per environment in this launch before it is parked (>= max_steps: never)
+    int qslot;                 // which RolloutCtl::next
+    int rps;                   // rules per column of the LDS image
+    int ht;                    // slots of the exact-hit hash table (power of two >= 2 rps)
+};
+
+// ---- exact hits by lookup ----------------------------------------------------------------------------------------------
+// The rule base of a roll-out never changes, so "the lowest rule whose antecedents equal the observation's VE point" (an exact hit:
+// distance 0 <=> every antecedent equal, FIVEVagConcl_FRIRL_BestAct.c:89-93) is found through a hash table over the rules' VE
+// tuples, built once per workgroup: one probe per action and step instead of a compare + select per action and RULE in the sweep.
+constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t hash_mix(uint32_t hsh, double x)
+{
+    const double c = x + 0.0;                             // -0.0 and +0.0 are the same antecedent
+    const uint32_t lo = (uint32_t)__double2loint(c), hi = (uint32_t)__double2hiint(c);
+    hsh = (hsh ^ lo) * 0x9E3779B1u;
+    hsh = (hsh ^ hi) * 0x85EBCA6Bu;
+    return hsh ^ (hsh >> 15);
+}
+
+template <int NANT>
+__device__ __forceinline__ bool rule_equals(const double *col, int RPS, int r, const double (&key)[NANT])
+{
+    bool eq = true;
+#pragma unroll
+    for (int k = 0; k < NANT; k++) eq = eq && (col[k * RPS + r] == key[k]);
+    return eq;
+}
+
+template <int NANT>
+__device__ __forceinline__ void hash_insert(uint32_t *tab, int ht, const double *col, int RPS, int r)
+{
+    double key[NANT];
+    uint32_t hsh = 0u;
+#pragma unroll
+    for (int k = 0; k < NANT; k++) { key[k] = col[k * RPS + r]; hsh = hash_mix(hsh, key[k]); }
+    for (int i = 0; i < ht; i++) {
+        const uint32_t slot = (hsh + (uint32_t)i) & (uint32_t)(ht - 1);
+        const uint32_t cur = atomicCAS(&tab[slot], HT_EMPTY, (uint32_t)r);
+        if (cur == HT_EMPTY) return;
+        if (rule_equals<NANT>(col, RPS, (int)cur, key)) { atomicMin(&tab[slot], (uint32_t)r); return; }   // duplicates: the lowest index
+    }
+}
+
+// lowest rule with these antecedents, or FRIRL_HIP_NO_HIT; `hsh` = hash of key[0 .. NANT-2], the last antecedent is mixed in here
+template <int NANT>
+__device__ __forceinline__ unsigned hash_lookup(const uint32_t *tab, int ht, const double *col, int RPS, uint32_t hsh, const double (&key)[NANT])
+{
+    hsh = hash_mix(hsh, key[NANT - 1]);
+    for (int i = 0; i < ht; i++) {
+        const uint32_t cur = tab[(hsh + (uint32_t)i) & (uint32_t)(ht - 1)];
+        if (cur == HT_EMPTY) return FRIRL_HIP_NO_HIT;
+        if (rule_equals<NANT>(col, RPS, (int)cur, key)) return cur;
+    }
+    return FRIRL_HIP_NO_HIT;
+}
+
+template <int N>
+__device__ __forceinline__ void group_sum_n(double (&v)[N], int H)
+{
+    for (int off = 1; off < H; off <<= 1) {
+        double t[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) t[i] = __shfl_xor(v[i], off, FRIRL_WAVE);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = v[i] + t[i];
+    }
+}
+
+template <int NANT, int NA, int KIND, int H, bool EXCL>
+__global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+                                                                        const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
+                                                                        const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro,
+                                                                        RolloutCtl *__restrict__ ctl, const RolloutPark park, const RolloutPhase ph)
+{
+    constexpr int NS = NANT - 1;
+    extern __shared__ double col[];                       // [(NANT+1)][rps] rule base image, [2][NANT][U] tables (lds_tab), hash table, slot bytes
+    __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
+    const int RPS = ph.rps;
+    const int R = nrules[0];
+    if (R > RPS) {                                        // does not fit: the tiled kernel takes the whole call (uniform exit)
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->too_big = 1u;
+        return;
+    }
+    const unsigned n_in = ph.from_parked ? ctl->parked : (unsigned)Q;
+    if (ph.from_parked && !(n_in > ph.lo && n_in <= ph.hi)) return;
+    double *tab_s = col + (size_t)(NANT + 1) * RPS;
+    constexpr bool LT = KIND != FRIRL_HIP_ENV_CARTPOLE;   // small tables (41-point universes): universes and VE tables in LDS too
+    uint32_t *hash_s = reinterpret_cast<uint32_t *>(tab_s + (LT ? 2 * NANT * U : 0));
+    uint8_t *slot_s = reinterpret_cast<uint8_t *>(hash_s + ph.ht);
+    const int nj = (R + H - 1) / H;                       // rules per lane; the padding rules of the last round weigh exactly 0
+    for (int i = threadIdx.x; i < (NANT + 1) * RPS; i += RR_BLOCK) {
+        const int k = i / RPS, r = i - k * RPS;
+        // padding: first antecedent 1e150 away (squared distance ~1e300, its weight underflows to 0), consequent 0
+        col[i] = (r < R) ? rb[(size_t)k * maxR + r] : (k == 0 ? 1.0e150 : 0.0);
+    }
+    if (EXCL) for (int r = threadIdx.x; r < RPS; r += RR_BLOCK) slot_s[r] = (r < R) ? ro.rule_slot[r] : (uint8_t)255;
+    for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += RR_BLOCK) grid_s[i] = ag.grid_values[i];
+    if (LT) for (int i = threadIdx.x; i < NANT * U; i += RR_BLOCK) { tab_s[i] = ve[i]; tab_s[NANT * U + i] = u[i]; }
+    for (int i = threadIdx.x; i < ph.ht; i += RR_BLOCK) hash_s[i] = HT_EMPTY;
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += RR_BLOCK) hash_insert<NANT>(hash_s, ph.ht, col, RPS, r);
+    __syncthreads();                                      // the last barrier: from here on every wave runs on its own
+    const double *ves, *us;
+    if constexpr (LT) { ves = tab_s; us = tab_s + NANT * U; } else { ves = ve; us = u; }
+    double udiv[NS];                                      // FIVEInit.c:244-248, once instead of per observation
+#pragma unroll
+    for (int k = 0; k < NS; k++) udiv[k] = universe_div(us + (size_t)k * U, U);
+    auto observe = [&](int k, double x) { const double *uni = us + (size_t)k * U; return ves[(size_t)k * U + snap_index(uni, U, x, udiv[k])]; };
+
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), h = lane % H;
+    const bool leader = (h == 0);
+    const auto pk = pin_pow(PowC<NANT>());
+    double ave[NA];                                       // uniform loads: the action VE points stay in scalar registers
+#pragma unroll
+    for (int a = 0; a < NA; a++) ave[a] = ag.action_ve[a];
+
+    double states[NS], q[NS], cur[NS], total = 0.0, action = 0.0;
+    int qi = 0, steps = 0, lsteps = 0, success = 0;
+    uint32_t mask = 0u;
+    bool active = false, fresh = false, drained = false;
+#pragma unroll
+    for (int k = 0; k < NS; k++) { states[k] = 0.0; q[k] = 0.0; cur[k] = 0.0; }
+
+    for (;;) {
+        // ---- refill: every idle group takes the next item of the in-order queue (one atomic per wave) ----------------
+        const bool want = !active && !drained;
+        const unsigned long long wb = __ballot(want && leader);
+        if (wb) {
+            const int first = __ffsll((long long)wb) - 1;
+            unsigned base = 0u;
+            if (lane == first) base = atomicAdd(&ctl->next[ph.qslot], (unsigned)__popcll(wb));
+            base = (unsigned)__shfl((int)base, first);
+            unsigned item = base + (unsigned)__popcll(wb & ((1ull << lane) - 1ull));
+            item = (unsigned)__shfl((int)item, lane - h);
+            if (want) {
+                if (item < n_in) {
+                    active = true;
+                    lsteps = 0;
+                    success = 0;
+                    if (ph.from_parked) {
+                        qi = park.env[item];
+                        steps = park.steps[item];
+                        total = park.total[item];
+                        action = grid_s[NS * FRIRL_HIP_MAX_GRID + park.act[item]];
+#pragma unroll
+                        for (int k = 0; k < NS; k++) states[k] = park.states[(size_t)item * NS + k];
+                        fresh = false;
+                    } else {
+                        qi = (int)item;
+                        steps = 0;
+                        total = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NS; k++) states[k] = ro.start_states ? ro.start_states[(size_t)qi * NS + k] : ag.values_def[k];   // frirl_episode.c:46-48
+                        fresh = true;
+                    }
+                    mask = (EXCL && ro.exclude_mask) ? ro.exclude_mask[qi] : 0u;
+                } else {
+                    drained = true;
+                }
+            }
+        }
+        if (!__any(active ? 1 : 0)) break;                // the queue is empty and every episode of this wave has ended
+
+        // ---- the environment's own step (every lane of the group computes the same values) ---------------------------
+        if (active) {
+            if (fresh) {
+#pragma unroll
+                for (int k = 0; k < NS; k++) q[k] = observe(k, states[k]);                  // :78 (un-quantised start state)
+            } else {
+                double r, qs[NS];
+                env_do_action(KIND, action, states, cur);                                         // :97
+                env_get_reward(KIND, cur, r, success);                                            // :106
+                total = total + r;                                                                       // :107
+                env_quantize(KIND, NS, grid_s, ag.grid_len, ag.grid_div, cur, qs);                // :112
+#pragma unroll
+                for (int k = 0; k < NS; k++) q[k] = observe(k, qs[k]);
+            }
+        }
+
+        // ---- frirl_get_best_action (:148): this lane's rules, all actions --------------------------------------------
+        double sv[NA], sw[NA];
+        unsigned sh[NA];
+#pragma unroll
+        for (int a = 0; a < NA; a++) { sv[a] = 0.0; sw[a] = 0.0; sh[a] = FRIRL_HIP_NO_HIT; }
+        if (active) {
+            // exact hits: one table probe per action; a hit's own sums come out of the sweep poisoned (rsq(0)) and are not read
+            double key[NANT];
+            uint32_t hs = 0u;
+#pragma unroll
+            for (int k = 0; k < NS; k++) { key[k] = q[k]; hs = hash_mix(hs, q[k]); }
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                key[NS] = ave[a];
+                unsigned f = hash_lookup<NANT>(hash_s, ph.ht, col, RPS, hs, key);
+                if (EXCL && f != FRIRL_HIP_NO_HIT) {
+                    const unsigned sl = slot_s[f];
+                    if (sl < 32u && ((mask >> sl) & 1u)) {      // the hit rule is removed: a later duplicate, if any, takes its place
+                        unsigned g = FRIRL_HIP_NO_HIT;
+                        for (int r = (int)f + 1; r < R && g == FRIRL_HIP_NO_HIT; r++) {
+                            const unsigned s2 = slot_s[r];
+                            if (!(s2 < 32u && ((mask >> s2) & 1u)) && rule_equals<NANT>(col, RPS, r, key)) g = (unsigned)r;
+                        }
+                        f = g;
+                    }
+                }
+                sh[a] = f;
+            }
+#pragma unroll 2
+            for (int j = 0; j < nj; j++) {
+                const int r = j * H + h;
+                const double d0 = q[0] - col[r];
+                double s = d0 * d0;
+#pragma unroll
+                for (int k = 1; k < NS; k++) { const double d = q[k] - col[k * RPS + r]; s = __fma_rn(d, d, s); }
+                const double va = col[NS * RPS + r], cq = col[NANT * RPS + r];
+                if (EXCL) {                               // a removed rule weighs exactly 0 (same sums as the compacted rule base)
+                    const unsigned sl = slot_s[r];
+                    s = (sl < 32u && ((mask >> sl) & 1u)) ? NO_RULE_STATE_PART : s;
+                }
+#pragma unroll
+                for (int a = 0; a < NA; a++) {
+                    const double e = ave[a] - va;
+                    const double d2 = __fma_rn(e, e, s);
+                    const double wi = shepard_w(d2, pk);
+                    sv[a] = __fma_rn(wi, cq, sv[a]);
+                    sw[a] = sw[a] + wi;
+                }
+            }
+        }
+        if (H > 1) {                                      // combine the H rule slices (all lanes of the wave take part in the moves)
+            group_sum_n<NA>(sv, H);
+            group_sum_n<NA>(sw, H);
+        }
+        if (active) {
+            // first maximum in action order, `bv < c` as max.inl:21; action 0 seeds it (a NaN there sticks, as in the reference)
+            double bv = 0.0;
+            int pa = 0;
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                const double c = (sh[a] != FRIRL_HIP_NO_HIT) ? col[NANT * RPS + (int)sh[a]] : sv[a] / sw[a];
+                if (a == 0 || bv < c) { bv = c; pa = a; }
+            }
+            bool ended = false;
+            if (fresh) {
+                pa = e_greedy(ag, pa, (uint32_t)qi, 0u, 0u);
+                fresh = false;
+            } else {
+                pa = e_greedy(ag, pa, (uint32_t)qi, 0u, (uint32_t)(steps + 1));
+#pragma unroll
+                for (int k = 0; k < NS; k++) states[k] = cur[k];                                         // :163-165
+                steps++;                                                                                 // :174
+                lsteps++;
+                if (success == 1) ended = true;                                                          // :183
+            }
+            action = grid_s[NS * FRIRL_HIP_MAX_GRID + pa];                                               // :82 / :151
+            if (!ended && steps >= ag.max_steps) ended = true;                                           // :86
+            if (ended) {
+                active = false;
+                if (leader) {
+                    ro.steps[qi] = steps;
+                    ro.reward[qi] = total;
+                    if (ro.success) ro.success[qi] = success;
+                    if (ro.final_states)
+                        for (int k = 0; k < NS; k++) ro.final_states[(size_t)qi * NS + k] = states[k];
+                }
+            } else if (lsteps >= ph.cap) {                // a long episode: a later launch finishes it with a whole wave
+                active = false;
+                if (leader) {
+                    const unsigned w = atomicAdd(&ctl->parked, 1u);
+                    park.env[w] = qi;
+                    park.steps[w] = steps;
+                    park.total[w] = total;
+                    park.act[w] = pa;
+                    for (int k = 0; k < NS; k++) park.states[(size_t)w * NS + k] = states[k];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace frirl
+
+using namespace frirl_host;
+
+namespace {
+
+int g_cus = 0;
+int device_cus()
+{
+    if (g_cus) return g_cus;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    g_cus = n;
+    return n;
+}
+
+template <int N, int NA, int KIND, int H>
+void launch_phase(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                  frirl::RolloutCtl *ctl, const frirl::RolloutPark &park, const frirl::RolloutPhase &ph, unsigned items_max, int wps, hipStream_t s)
+{
+    const bool excl = ro->exclude_mask && ro->rule_slot;
+    const size_t dyn = (size_t)(N + 1) * ph.rps * sizeof(double) + (KIND != FRIRL_HIP_ENV_CARTPOLE ? 2 * sizeof(double) * N * (size_t)t->U : 0) + sizeof(uint32_t) * (size_t)ph.ht +
+                       (excl ? (size_t)ph.rps : 0);
+    const long need = ((long)items_max * H + frirl::RR_BLOCK - 1) / frirl::RR_BLOCK;
+    const long cap = (long)wps * device_cus();
+    const dim3 grid((unsigned)(need < cap ? (need < 1 ? 1 : need) : cap));
+    if (excl)
+        hipLaunchKernelGGL((frirl::rollout_resident_kernel<N, NA, KIND, H, true>), grid, dim3(frirl::RR_BLOCK), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro, ctl, park, ph);
+    else
+        hipLaunchKernelGGL((frirl::rollout_resident_kernel<N, NA, KIND, H, false>), grid, dim3(frirl::RR_BLOCK), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro, ctl, park, ph);
+}
+
+template <int N, int NA, int KIND>
+void launch_phase_h(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                    frirl::RolloutCtl *ctl, const frirl::RolloutPark &park, const frirl::RolloutPhase &ph, unsigned items_max, int wps, hipStream_t s)
+{
+    if constexpr (NA <= 8) { if (H == 64) { launch_phase<N, NA, KIND, 64>(t, b, ag, Q, ro, ctl, park, ph, items_max, wps, s); return; } }
+    if (H >= 16) launch_phase<N, NA, KIND, 16>(t, b, ag, Q, ro, ctl, park, ph, items_max, wps, s);
+    else launch_phase<N, NA, KIND, 4>(t, b, ag, Q, ro, ctl, park, ph, items_max, wps, s);
+}
+
+}  // namespace
+
+// rules per LDS column the resident form can hold (0: shape not covered -> the tiled kernel)
+extern "C" int frirl_hip_rollout_resident_rules(int32_t nant, int32_t A, int32_t p, int32_t env_kind)
+{
+    const bool shape = (env_kind == FRIRL_HIP_ENV_MOUNTAINCAR && nant == 3 && A == 3) || (env_kind == FRIRL_HIP_ENV_ACROBOT && nant == 5 && A == 3) ||
+                       (env_kind == FRIRL_HIP_ENV_CARTPOLE && nant == 5 && A == 21);       // the demos' shapes; anything else: the tiled kernel
+    if (!shape || (p > 0 && p != nant)) return 0;
+    if (opts().rollout_resident == 0) return 0;
+    return (40 * 1024) / ((nant + 1) * 8 + 1 + 8) / 64 * 64;      // image + slot byte + 2 hash slots per rule in <= 40 KiB
+}
+
+// Returns 1 when the resident phases were enqueued (*ctl_out: control block whose too_big flag tells the tiled kernel, launched
+// after them by the caller when maxR exceeds the LDS image, whether it has to run), 0 when the shape is not covered.
+int frirl_rollout_resident(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                           hipStream_t s, const unsigned **too_big_flag, void **workspace)
+{
+    *too_big_flag = nullptr;
+    *workspace = nullptr;
+    const int cap_rules = frirl_hip_rollout_resident_rules(t->nant, ag->A, ag->p, ag->env_kind);
+    if (!cap_rules) return 0;
+    if (ag->env_kind != FRIRL_HIP_ENV_CARTPOLE && 2 * sizeof(double) * t->nant * (size_t)t->U > 16 * 1024) return 0;   // their tables go to LDS
+    const int NS = t->nant - 1;
+    const int rps_full = (b->maxR + 63) / 64 * 64;
+    const int rps = rps_full < cap_rules ? rps_full : cap_rules;
+    // workspace: control block + park lists, stream-ordered
+    const size_t q8 = ((size_t)Q + 1) / 2 * 2;
+    const size_t bytes = 64 + q8 * (sizeof(int32_t) * 3 + sizeof(double) * (NS + 1));
+    char *ws = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&ws), bytes, s) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    (void)hipMemsetAsync(ws, 0, 64, s);
+    frirl::RolloutCtl *ctl = reinterpret_cast<frirl::RolloutCtl *>(ws);
+    frirl::RolloutPark park;
+    park.states = reinterpret_cast<double *>(ws + 64);
+    park.total = park.states + q8 * NS;
+    park.env = reinterpret_cast<int32_t *>(park.total + q8);
+    park.steps = park.env + q8;
+    park.act = park.steps + q8;
+
+    const Options &o = opts();
+    int HA = Q <= 2048 ? 64 : (Q <= 16384 ? 16 : 4);
+    if (o.rollout_slices == 4 || o.rollout_slices == 16 || o.rollout_slices == 64) HA = o.rollout_slices;
+    if (ag->A > 8 && HA == 64) HA = 16;                     // many actions: the butterfly over 64 lanes would outweigh 3 rules per lane
+    const int wps = (o.rollout_wps >= 1 && o.rollout_wps <= 4) ? o.rollout_wps : 2;
+    int cap = ag->max_steps;
+    if (HA != 64 && !(ag->A > 8 && HA == 16)) {
+        cap = ag->max_steps / 6;
+        if (cap < 64) cap = 64;
+        if (o.rollout_cap > 0) cap = o.rollout_cap;
+    }
+    if (cap >= ag->max_steps) cap = ag->max_steps > 0 ? ag->max_steps : 1;
+    const bool parks = cap < ag->max_steps;
+
+    frirl::RolloutPhase ph = {};
+    ph.rps = rps;
+    ph.ht = 64;
+    while (ph.ht < 2 * rps) ph.ht *= 2;
+    ph.cap = cap;
+    ph.qslot = 0;
+#define PHASE(HH, items)                                                                                                        \
+    do {                                                                                                                        \
+        if (t->nant == 3) launch_phase_h<3, 3, FRIRL_HIP_ENV_MOUNTAINCAR>(HH, t, b, ag, Q, ro, ctl, park, ph, items, wps, s);    \
+        else if (ag->A == 3) launch_phase_h<5, 3, FRIRL_HIP_ENV_ACROBOT>(HH, t, b, ag, Q, ro, ctl, park, ph, items, wps, s);    \
+        else launch_phase_h<5, 21, FRIRL_HIP_ENV_CARTPOLE>(HH, t, b, ag, Q, ro, ctl, park, ph, items, wps, s);                  \
+    } while (0)
+    PHASE(HA, (unsigned)Q);
+    if (parks) {
+        // the parked episodes, finished by the launch whose range holds their number (the others return at once)
+        const int HL = ag->A > 8 ? 16 : 64;                 // latency form
+        ph.from_parked = 1;
+        ph.cap = ag->max_steps;
+        ph.qslot = 1; ph.lo = 0u; ph.hi = 2048u;
+        PHASE(HL, (unsigned)(Q < 2048 ? Q : 2048));
+        if (Q > 2048) {
+            ph.qslot = 2; ph.lo = 2048u; ph.hi = HA == 4 ? 16384u : 0xffffffffu;
+            PHASE(16, (unsigned)(Q < 16384 || HA != 4 ? Q : 16384));
+        }
+        if (Q > 16384 && HA == 4) {
+            ph.qslot = 3; ph.lo = 16384u; ph.hi = 0xffffffffu;
+            PHASE(4, (unsigned)Q);
+        }
+    }
+#undef PHASE
+    *too_big_flag = rps_full > cap_rules ? &ctl->too_big : nullptr;
+    *workspace = ws;
+    return 1;
+}

@@ -36,6 +36,11 @@ static const OptName k_opts[] = {
     {"lanes_wpe", "FRIRL_HIP_LANES_WPE", &Options::lanes_wpe, 0},
     {"rollout_group", "FRIRL_HIP_ROLLOUT_GROUP", &Options::rollout_group, 0},
     {"rollout_slices", "FRIRL_HIP_ROLLOUT_SLICES", &Options::rollout_slices, 0},
+    {"rollout_resident", "FRIRL_HIP_ROLLOUT_RESIDENT", &Options::rollout_resident, -1},
+    {"rollout_cap", "FRIRL_HIP_ROLLOUT_CAP", &Options::rollout_cap, 0},
+    {"rollout_wps", "FRIRL_HIP_ROLLOUT_WPS", &Options::rollout_wps, 0},
+    {"learn_slices", "FRIRL_HIP_LEARN_SLICES", &Options::learn_slices, 0},
+    {"learn_persistent", "FRIRL_HIP_LEARN_PERSISTENT", &Options::learn_persistent, -1},
     {"no_many", "FRIRL_HIP_NO_MANY", &Options::no_many, 0},
     {"mirror_sync", "FRIRL_HIP_MIRROR_SYNC", &Options::mirror_sync, 0},
 };

@@ -193,9 +193,11 @@ __device__ __forceinline__ void group_first_max(double &bv, int &bi)
 template <int NANT, int AMAX, int G, int H, bool EXCL, bool PN = true>
 __global__ __launch_bounds__(SH_BLOCK) void rollout_shared_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                                    const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
-                                                                   const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro)
+                                                                   const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro,
+                                                                   const unsigned *__restrict__ run_if)
 {
     constexpr int NS = NANT - 1, GH = G * H, EPB = SH_BLOCK / GH;
+    if (run_if && *run_if == 0u) return;          // the resident form (rollout.hip) has served this call
     __shared__ SharedTile<NANT> tl;
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
     const int gl = threadIdx.x % GH, sub = gl % G, h = gl / G;      // group lane = (rule slice h, action slot sub)
@@ -314,14 +316,14 @@ extern "C" int frirl_hip_get_best_action_shared(const frirl_hip_tables *t, const
 
 template <int N, int AMAX, int G, int H, bool PN = true>
 static void launch_rollout(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
-                           hipStream_t s)
+                           hipStream_t s, const unsigned *run_if)
 {
     constexpr int EPB = frirl::SH_BLOCK / (G * H);
     const dim3 grid((Q + EPB - 1) / EPB);
     if (ro->exclude_mask && ro->rule_slot)
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, true, PN>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, true, PN>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro, run_if);
     else
-        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, false, PN>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro);
+        hipLaunchKernelGGL((frirl::rollout_shared_kernel<N, AMAX, G, H, false, PN>), grid, dim3(frirl::SH_BLOCK), 0, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro, run_if);
 }
 
 // lanes per environment: 1 once the environments alone fill the chip, else split the actions over 4 (A <= 4) or 8 lanes
@@ -344,31 +346,34 @@ static int rollout_slices(int Q, int G)
 
 template <int N, int AMAX, int G>
 static void launch_rollout_h(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
-                             hipStream_t s)
+                             hipStream_t s, const unsigned *run_if)
 {
     const int H = rollout_slices(Q, G);
-    if (H == 8) launch_rollout<N, AMAX, G, 8>(t, b, ag, Q, ro, s);
-    else if (H == 4) launch_rollout<N, AMAX, G, 4>(t, b, ag, Q, ro, s);
-    else launch_rollout<N, AMAX, G, 1>(t, b, ag, Q, ro, s);
+    if (H == 8) launch_rollout<N, AMAX, G, 8>(t, b, ag, Q, ro, s, run_if);
+    else if (H == 4) launch_rollout<N, AMAX, G, 4>(t, b, ag, Q, ro, s, run_if);
+    else launch_rollout<N, AMAX, G, 1>(t, b, ag, Q, ro, s, run_if);
 }
 
 template <int N>
 static void launch_rollout_n(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
-                             hipStream_t s)
+                             hipStream_t s, const unsigned *run_if)
 {
     const int G = rollout_group(Q, ag->A);
     if (ag->p > 0 && ag->p != N) {          // run-time Shepard power: the variants without rule slices
-        if (G == 4) launch_rollout<N, 1, 4, 1, false>(t, b, ag, Q, ro, s);
-        else if (G == 8) launch_rollout<N, 4, 8, 1, false>(t, b, ag, Q, ro, s);
-        else if (ag->A <= 4) launch_rollout<N, 4, 1, 1, false>(t, b, ag, Q, ro, s);
-        else launch_rollout<N, 8, 1, 1, false>(t, b, ag, Q, ro, s);
+        if (G == 4) launch_rollout<N, 1, 4, 1, false>(t, b, ag, Q, ro, s, run_if);
+        else if (G == 8) launch_rollout<N, 4, 8, 1, false>(t, b, ag, Q, ro, s, run_if);
+        else if (ag->A <= 4) launch_rollout<N, 4, 1, 1, false>(t, b, ag, Q, ro, s, run_if);
+        else launch_rollout<N, 8, 1, 1, false>(t, b, ag, Q, ro, s, run_if);
         return;
     }
-    if (G == 4) launch_rollout_h<N, 1, 4>(t, b, ag, Q, ro, s);
-    else if (G == 8) launch_rollout_h<N, 4, 8>(t, b, ag, Q, ro, s);
-    else if (ag->A <= 4) launch_rollout<N, 4, 1, 1>(t, b, ag, Q, ro, s);
-    else launch_rollout<N, 8, 1, 1>(t, b, ag, Q, ro, s);
+    if (G == 4) launch_rollout_h<N, 1, 4>(t, b, ag, Q, ro, s, run_if);
+    else if (G == 8) launch_rollout_h<N, 4, 8>(t, b, ag, Q, ro, s, run_if);
+    else if (ag->A <= 4) launch_rollout<N, 4, 1, 1>(t, b, ag, Q, ro, s, run_if);
+    else launch_rollout<N, 8, 1, 1>(t, b, ag, Q, ro, s, run_if);
 }
+
+int frirl_rollout_resident(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                           hipStream_t s, const unsigned **too_big_flag, void **workspace);      // rollout.hip
 
 extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, int32_t Q,
                                         const frirl_hip_rollout *ro, void *stream)
@@ -385,8 +390,20 @@ extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_h
         return FRIRL_HIP_EINVAL;
     }
     hipStream_t s = as_stream(stream);
-    if (t->nant == 3) launch_rollout_n<3>(t, b, agent, Q, ro, s);
-    else launch_rollout_n<5>(t, b, agent, Q, ro, s);
+    // small rule bases: the LDS-resident, queue-fed form (rollout.hip); the tiled kernel below serves every other shape, and a rule
+    // base that turns out not to fit the LDS image (known on the device only: `too_big`)
+    const unsigned *too_big = nullptr;
+    void *ws = nullptr;
+    if (frirl_rollout_resident(t, b, agent, Q, ro, s, &too_big, &ws)) {
+        if (too_big) {
+            if (t->nant == 3) launch_rollout_n<3>(t, b, agent, Q, ro, s, too_big);
+            else launch_rollout_n<5>(t, b, agent, Q, ro, s, too_big);
+        }
+        (void)hipFreeAsync(ws, s);
+        return check_launch("frirl_hip_rollout_shared");
+    }
+    if (t->nant == 3) launch_rollout_n<3>(t, b, agent, Q, ro, s, nullptr);
+    else launch_rollout_n<5>(t, b, agent, Q, ro, s, nullptr);
     return check_launch("frirl_hip_rollout_shared");
 }
 

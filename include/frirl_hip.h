@@ -97,7 +97,7 @@ int frirl_hip_device_count(void);                 /* number of visible gfx950 de
 int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, int64_t *hbm_bytes);
 
 /* Experiment / test switches by name: "no_uidx" (1 = ignore the 16-bit index mirror), "rd_unroll", "rd_chunk", "rd_nt",
- * "rd_persist", "rd_order", "step_wave", "step_track", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices", "no_many", "mirror_sync".  Their defaults
+ * "rd_persist", "rd_order", "step_wave", "step_track", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices", "rollout_resident", "rollout_cap", "rollout_wps", "learn_slices", "learn_persistent", "no_many", "mirror_sync".  Their defaults
  * (the shipped configuration) are read ONCE from the matching FRIRL_HIP_<NAME> environment variable, never per launch;
  * results do not depend on any of them (only the kernel variant / launch shape does). */
 int frirl_hip_set_option(const char *name, int value);
@@ -192,6 +192,10 @@ typedef struct frirl_hip_rollout {
 } frirl_hip_rollout;
 int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, int32_t Q,
                              const frirl_hip_rollout *ro, void *stream);
+/* Rule-base size up to which frirl_hip_rollout_shared runs its LDS-resident, queue-fed form for this shape (csrc/rollout.hip: the
+ * whole rule base in LDS, H = 4 / 16 / 64 lanes per environment splitting the rules, finished groups refilled from an in-order
+ * queue, long episodes parked and finished by whole waves, exact hits by hash lookup); 0 = the tiled kernel serves the shape. */
+int frirl_hip_rollout_resident_rules(int32_t nant, int32_t A, int32_t p, int32_t env_kind);
 
 /* Rule-base reduction (reference frirl_sequential_run.c:170-350, strategies 1 = smallest |Q| first, 2 = largest |Q|
  * first) as a batched "try-remove" on the GPU.  The reference tests ONE candidate per replayed episode: remove it, replay
@@ -318,6 +322,29 @@ size_t frirl_hip_lanes_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, in
 int frirl_hip_lanes_preferred(int32_t nant, int32_t E, int32_t A);
 int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent,
                                 const frirl_hip_envs *envs, int32_t nsteps, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The whole construct loop of frirl_sequential_run (reference src/frirl/frirl_sequential_run.c:55-165) for many agents with small
+ * rule bases, persistent: every agent of `live` ([dev] nlive agent ids, NULL = agents 0..nlive-1) runs episode after episode at its
+ * own pace -- frirl_episode's loop, the SARSA update and, at each episode's end, the loop's bookkeeping (same rule count, steps and
+ * good reward as the previous episode and no consequent moved by qdiff_final_tolerance => "RB considered complete", :83-148; then the
+ * snapshot, :68-72) -- until it has converged, has made budget_steps steps in this call, or has run max_episodes - 1 episodes
+ * (:51,59).  Nothing in a launch waits for the longest episode of the batch: the reference's many-agent modes diversify the start
+ * states (frirl_agent.c:121-139), so agents are never in step.  Between calls the host compacts the agents that are still learning
+ * into `live`; the fewer they are, the more lanes each gets (4 / 16 / 64 rule slices per agent).
+ * State: envs->done[e] != 0 on entry means "between two episodes" (set it to 1 for a fresh agent; frirl_hip_convergence_init first);
+ * on return done[e] = 1 iff the agent stopped at an episode boundary, ep_steps / ep_reward = the running or last episode,
+ * conv->episodes / converged / prev_* as frirl_hip_convergence_update leaves them, status[e] = FRIRL_HIP_UPD_FULL iff an append was
+ * refused.  work ([dev][E][2] int64, or NULL) accumulates the rule visits of the fused sweeps (one visit = one rule evaluated for
+ * all A + 1 conclusions of a step) and of the extra single-conclusion sweeps (snapped point, weighted spread); steps_total
+ * ([dev][E] int64, or NULL) the environment steps.  Needs the 16-bit index mirror.  Covered shapes: frirl_hip_learn_supported
+ * (mountaincar and acrobot: 3 actions, universes of <= 64 points; cartpole's 21 actions stay with frirl_hip_episode_run_lanes).
+ * Decisions follow the oracle exactly on the demos (tests/test_hip_learn.py); interpolated Q within the 1e-6 contract (per-lane sums in
+ * descending rule order, slices added in butterfly order). */
+int frirl_hip_learn_supported(int32_t nant, int32_t U, int32_t A, int32_t p, int32_t env_kind);
+size_t frirl_hip_learn_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
+int frirl_hip_learn_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
+                        const frirl_hip_convergence *conv, const int32_t *live, int32_t nlive, int32_t budget_steps, int32_t max_episodes,
+                        int64_t *work, int64_t *steps_total, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Persistent form for SMALL rule bases (the demos' learning regime): one wave keeps its environment's rule base,
  * the tables and the episode state in LDS and runs up to nsteps consecutive steps without a global round trip per
