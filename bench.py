@@ -257,6 +257,21 @@ class Bench:
             plain = frirl_amd.Problem(prob.u, prob.ve, prob.rb, prob.nrules)
             _, f64_ms = self.timed(lambda: plain.rule_distance(x, ruledists=dists, hit=hit, stream=self.stream), max(steps // 3, 5), 2)
         nhits = float((hit >= 0).sum().item())
+        # parity gate, outside the timed region: sampled environments (first, last, middle, either side of work-item batch edges)
+        # against the oracle -- distances bit-exact and the exact-hit index, for every layout that was timed
+        from tests import gates
+        sample = gates.spread_sample(E, 8, boundaries=(256, E // 4, E - 256))
+        gate = gates.gate_rule_distance(prob, x, dists, hit, sample)
+        gate["layouts"] = ["u16 index mirror" if compressed else "f64 columns"]
+        if compressed:
+            d2 = torch.empty_like(dists)
+            h2 = torch.empty_like(hit)
+            plain.rule_distance(x, ruledists=d2, hit=h2, stream=self.stream)
+            torch.cuda.synchronize()
+            gates.gate_rule_distance(plain, x, d2, h2, sample)
+            assert (h2 == hit).all(), "the two layouts disagree on an exact-hit index"
+            gate["layouts"].append("f64 columns")
+            del d2, h2
         del dists
         evals = float(E) * R
         contract_bytes = 8.0 * (nant + 1) * evals              # the reference's f64 SoA layout, 8*nant read + 8 written per eval
@@ -283,7 +298,7 @@ class Bench:
                 roof["traffic_kernel"] = tr.get("kernel")
         except (OSError, ValueError):
             pass
-        return {"evals_per_s_rank": evals * steps / dt, "wall_s": dt, "exact_hits_rank": nhits}, roof
+        return {"evals_per_s_rank": evals * steps / dt, "wall_s": dt, "exact_hits_rank": nhits, "parity_gate": gate}, roof
 
     def env_steps_leg(self, w, prob, agent, envs, nsteps, warmup):
         """The metric's second half: whole environment steps (do_action, reward, quantise, greedy sweep, SARSA update)."""
@@ -292,6 +307,11 @@ class Bench:
         E, R, nant = w["E"], w["R"], w["nant"]
         frirl_amd.episode_begin(prob, agent, envs, stream=self.stream)
         edt, ems = self.timed(lambda: frirl_amd.episode_step(prob, agent, envs, stream=self.stream), nsteps, warmup)
+        # parity gate, outside the timed region: ONE more step of the whole batch; sampled environments replayed by the oracle from a
+        # snapshot (state, chosen action, rule count and appended antecedents exact, consequents <= 1e-9)
+        from tests import gates
+        gate = gates.gate_env_step(prob, agent, envs, w["env"], gates.spread_sample(E, 8, boundaries=(E // 4,)),
+                                   lambda: frirl_amd.episode_step(prob, agent, envs, stream=self.stream))
         # per-episode reward statistics: the ONLY cross-rank exchange (RCCL all-reduce over xGMI when N > 1)
         st = self.D.allreduce_stats(envs.ep_reward, envs.ep_steps, envs.done, prob.nrules)
         status = torch.bincount(envs.status.long(), minlength=6).tolist()
@@ -306,6 +326,7 @@ class Bench:
                "stats_allreduce": {"envs": st.envs, "mean_reward": st.mean_reward, "mean_rules": st.mean_rules, "steps_sum": st.steps_sum,
                                    "episodes_done": st.success, "reward_min": st.reward_min, "reward_max": st.reward_max},
                "last_step_outcomes_rank0": dict(zip(["inactive", "exact", "spread", "inserted", "skipped", "full"], status)),
+               "parity_gate": gate,
                "note": "moved_* = one pass over the rule-base slabs per step (the fused sweep; compressed antecedents where the step kernel uses "
                        "them); fp64_issue = the step's second roofline: algorithmic FP64 vector-instruction slots of the fused sweep / the "
                        "chip's FP64 vector issue rate (many actions: issue-bound; 3 actions at 65 536 rules: between the two)"}
@@ -327,61 +348,120 @@ def fp64_issue(E, R, nant, A, ms):
             "peak_source": "FP64 vector 78.6 TFLOP/s (half the FP32 vector peak of MI355X_MICROARCH.md: 16 lanes per clock and SIMD at 2.4 GHz) = 3.93e13 lane-instructions/s; a v_fma_f64 stream alone reaches 0.82 of it (profiles/r02_valu_cost.txt)"}
 
 
+LEARN_AGENTS = 65536          # agents per GPU of the learning legs (the many-agent regime; weak scaling)
+
+
+def issue_record(slots, seconds, extra):
+    peak = FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0
+    rec = {"bound": "fp64-issue", "achieved_lane_instr_per_s": slots / seconds, "peak_lane_instr_per_s": peak, "frac": slots / seconds / peak,
+           "how": "COUNTED work: rule visits accumulated by the kernel itself x algorithmic FP64 vector-instruction slots per visit (14.4 per conclusion: 2 squared "
+                  "distance + 3.4 rsq + 7 series / power + 2 sums; + 2 per state dimension and sweep) / wall time / 3.93e13 lane-instructions/s"}
+    rec.update(extra)
+    return rec
+
+
+def grid_start_states(d, E, device, seed):
+    """One start state per agent on the state grid (the reference's many-agent modes give every agent its own start state:
+    gen_def_states takes them from the master's rule antecedents, which lie on this grid; frirl_agent.c:121-139)."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    cols = []
+    for k in range(d["nstates"]):
+        vals = torch.from_numpy(d["grids"][k]).to(device)
+        cols.append(vals[torch.randint(0, len(vals), (E,), generator=g, device=device)])
+    return torch.stack(cols, 1).contiguous()
+
+
 def learning_and_evaluation(B, w, world, rank):
-    """Legs 3 and 4: real learning (E agents from the reference's initial 2^nant rule base until every rule base is
-    "considered complete": batched frirl_sequential_run construct loop, all on the device) and evaluation (greedy
-    roll-outs of 65 536 environments on ONE shared rule base, the one agent 0 just learned)."""
+    """Legs 3-5: real learning -- E agents from the reference's initial 2^nant corner rule base until every rule base is "considered
+    complete" (frirl_sequential_run's construct loop, all on the device) -- as REPLICAS of the demo (every agent the same start state:
+    identical trajectories, the best case) and with DIVERSIFIED start states (the reference's many-agent regime: agents never in step,
+    converging after anything between a few hundred and tens of thousands of steps, some not within max_episodes); and evaluation:
+    greedy roll-outs of 65 536 environments on ONE shared rule base (the one agent 0 of the replica run learned)."""
     import torch
     import torch.distributed as dist
     import frirl_amd
     device, D = B.device, B.D
-    lE = min(w["E"], 8192)
-    lprob, lagent, lenvs = frirl_amd.demo_fresh_batch(w["env"], lE, 1024, device)
-    lsteps = torch.zeros((), dtype=torch.int64, device=device)
-    ep_log = []
+    env = w["env"]
+    dd = frirl_amd.demo_describe(env)
+    nant, A = dd["nant"], len(dd["action_ve"])
+    wprob, wagent, wenvs = frirl_amd.demo_fresh_batch(env, 64, 1024, device)
+    persistent = frirl_amd.learn_supported(wprob, wagent)
+    legs = {}
+    one = None
+    if persistent:
+        frirl_amd.train_persistent(wprob, wagent, wenvs, max_episodes=3, budget=64)      # untimed: loads the code objects
+        del wprob, wenvs
+        for name, diversify, max_episodes in (("learning", False, 1000), ("learning_diversified", True, 200)):
+            start = grid_start_states(dd, LEARN_AGENTS, device, 1 + rank) if diversify else None
+            lprob, lagent, lenvs = frirl_amd.demo_fresh_batch(env, LEARN_AGENTS, 1024, device, start_states=start)
+            lagent.desc.env_id_base = rank * LEARN_AGENTS
+            chunks = []
 
-    def on_ep(ep, conv):
-        lsteps.add_((lenvs.ep_steps.long() * (conv.episodes == ep).long()).sum())
-        # the reference's per-episode report (frirl_sequential_run.c:74-77) for the whole job: reward statistics only
-        # cross the GPUs -- one tiny all-reduce per episode (RCCL over xGMI; latency-bound, overlaps the next episode)
-        st = torch.stack([lenvs.ep_reward.sum(), lenvs.ep_steps.sum().double(), lprob.nrules.sum().double(), conv.converged.sum().double()])
-        if world > 1:
-            dist.all_reduce(st)
-        ep_log.append(st)
-    # untimed warm-up: one short episode of a 64-agent batch loads the code objects of the episode kernels ...
-    wprob, wagent, wenvs = frirl_amd.demo_fresh_batch(w["env"], 64, 1024, device)
-    frirl_amd.train(wprob, wagent, wenvs, max_episodes=3)
-    del wprob, wagent, wenvs
-    # ... and one pass over the bookkeeping ops (first use of a torch kernel loads its code object: milliseconds each)
-    _w = torch.stack([lenvs.ep_reward.sum(), lenvs.ep_steps.sum().double(), lprob.nrules.sum().double(), torch.zeros((), device=device, dtype=torch.float64)])
-    _w2 = (lenvs.ep_steps.long() * (lprob.nrules == 1).long()).sum()
-    if world > 1:
-        dist.all_reduce(_w)
-    del _w, _w2
-    lanes = bool(frirl_amd.lib().frirl_hip_lanes_preferred(lprob.nant, lE, lagent.A))
-    if lanes:
-        frirl_amd.episode_run_lanes(lprob, lagent, lenvs, 0)      # allocates the transposed-rule-base workspace outside the timed region
-    B.sync_all()
-    t0 = time.perf_counter()
-    conv = frirl_amd.train(lprob, lagent, lenvs, on_episode=on_ep)
-    B.sync_all()
-    ldt = D.max_over_ranks(time.perf_counter() - t0, device)
-    tot = torch.tensor([float(lsteps.item()), float(conv.converged.sum().item()), float(lprob.nrules.sum().item()), float(conv.full_envs)],
-                       dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tot)
-    learn_leg = {"value": tot[0].item() / ldt, "unit": "env-steps/s", "agents": lE * world, "wall_s": ldt, "env_steps": tot[0].item(),
-                 "agents_converged": tot[1].item(), "episodes_to_converge": int(conv.episodes.max().item()),
-                 "mean_final_rules": tot[2].item() / (lE * world), "agents_with_refused_appends": tot[3].item(),
-                 "per_episode_stats_allreduce": {"episodes": len(ep_log), "last": dict(zip(["reward_sum", "steps_sum", "rules_sum", "converged"],
-                                                                                      [float(v) for v in ep_log[-1].tolist()])) if ep_log else None},
-                 "kernel": "episode_run_lanes (lane groups)" if lanes else "episode_run / episode_step (one wave per environment)",
-                 "note": "whole construct run from the 2^nant corner rules (reference: 15548 / 33002 / 21207 steps per agent for "
-                         "mountaincar / cartpole / acrobot); rule bases stay small (<= 367 rules): latency / occupancy bound at 8192 agents"}
+            def on_chunk(i, live, conv):
+                # the report of the many-agent job: reward statistics only cross the GPUs -- one tiny all-reduce per launch
+                st = torch.stack([lenvs.ep_reward.sum(), lenvs.ep_steps.sum().double(), lprob.nrules.sum().double(), conv.converged.sum().double()])
+                if world > 1:
+                    dist.all_reduce(st)
+                chunks.append((LEARN_AGENTS if live is None else int(live.numel()), st))
+            B.sync_all()
+            t0 = time.perf_counter()
+            run = frirl_amd.train_persistent(lprob, lagent, lenvs, max_episodes=max_episodes, budget=1024, on_chunk=on_chunk)
+            B.sync_all()
+            ldt = D.max_over_ranks(time.perf_counter() - t0, device)
+            wk = run.work.sum(0).double()
+            tot = torch.stack([run.steps_total.sum().double(), run.conv.converged.sum().double(), lprob.nrules.sum().double(),
+                               torch.tensor(float(run.conv.full_envs), device=device, dtype=torch.float64), wk[0], wk[1]])
+            if world > 1:
+                dist.all_reduce(tot)
+            tot = tot.tolist()
+            slots = tot[4] * (14.4 * (A + 1) + 4.0 * (nant - 1)) + tot[5] * (2.0 * nant + 10.4)
+            eps = run.conv.episodes
+            legs[name] = {"value": tot[0] / ldt, "unit": "env-steps/s", "agents": LEARN_AGENTS * world, "start_states": "per-agent, on the state grid" if diversify else "identical (replicas of the demo)",
+                          "wall_s": ldt, "env_steps": tot[0], "agents_converged": tot[1], "max_episodes": max_episodes,
+                          "episodes_min_max_rank0": [int(eps.min().item()), int(eps.max().item())], "mean_final_rules": tot[2] / (LEARN_AGENTS * world),
+                          "agents_with_refused_appends": tot[3], "launches": run.launches, "live_agents_per_launch_rank0": [c[0] for c in chunks][:64],
+                          "report_allreduce": {"launches": len(chunks), "last": dict(zip(["reward_sum", "steps_sum", "rules_sum", "converged"], [float(v) for v in chunks[-1][1].tolist()]))},
+                          "kernel": "learn_kernel (persistent construct loop, csrc/learn_kernel.h)",
+                          "fp64_issue": issue_record(slots, ldt, {"rule_visits_fused_sweeps": tot[4], "rule_visits_extra_sweeps": tot[5],
+                                                                  "slots_per_fused_visit": 14.4 * (A + 1) + 4.0 * (nant - 1), "slots_per_extra_visit": 2.0 * nant + 10.4})}
+            if not diversify:
+                assert bool((run.conv.converged == 1).all()), "the replicas of the demo must all converge"
+                one = frirl_amd.Problem(lprob.u, lprob.ve, lprob.rb[0:1].clone(), lprob.nrules[0:1].clone())
+                eagent = lagent
+            del lprob, lenvs, run
+            torch.cuda.empty_cache()
+        legs["learning_diversified"]["vs_replicas"] = legs["learning_diversified"]["fp64_issue"]["frac"] / legs["learning"]["fp64_issue"]["frac"]
+    else:
+        # cartpole (21 actions): one episode per launch through the lane groups of lanes.hip; no work counters in that kernel
+        lE = 8192
+        for name, diversify in (("learning", False), ("learning_diversified", True)):
+            start = grid_start_states(dd, lE, device, 1 + rank) if diversify else None
+            lprob, lagent, lenvs = frirl_amd.demo_fresh_batch(env, lE, 1024, device, start_states=start)
+            lsteps = torch.zeros((), dtype=torch.int64, device=device)
 
-    ns = lprob.nant - 1
-    dd = frirl_amd.demo_describe(w["env"])
-    one = frirl_amd.Problem(lprob.u, lprob.ve, lprob.rb[0:1].clone(), lprob.nrules[0:1].clone())
+            def on_ep(ep, conv):
+                lsteps.add_((lenvs.ep_steps.long() * (conv.episodes == ep).long()).sum())
+            frirl_amd.episode_run_lanes(lprob, lagent, lenvs, 0)
+            B.sync_all()
+            t0 = time.perf_counter()
+            conv = frirl_amd.train(lprob, lagent, lenvs, on_episode=on_ep, max_episodes=200 if diversify else 1000)
+            B.sync_all()
+            ldt = D.max_over_ranks(time.perf_counter() - t0, device)
+            tot = torch.tensor([float(lsteps.item()), float(conv.converged.sum().item()), float(lprob.nrules.sum().item())], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(tot)
+            legs[name] = {"value": tot[0].item() / ldt, "unit": "env-steps/s", "agents": lE * world, "wall_s": ldt, "env_steps": tot[0].item(),
+                          "agents_converged": tot[1].item(), "mean_final_rules": tot[2].item() / (lE * world),
+                          "start_states": "per-agent, on the state grid" if diversify else "identical (replicas of the demo)",
+                          "kernel": "episode_run_lanes (lane groups, one episode per launch)", "fp64_issue": None}
+            if not diversify:
+                one = frirl_amd.Problem(lprob.u, lprob.ve, lprob.rb[0:1].clone(), lprob.nrules[0:1].clone())
+                eagent = lagent
+            del lprob, lenvs
+            torch.cuda.empty_cache()
+
+    ns = nant - 1
     Qn = 65536
     g = torch.Generator(device=device)
     g.manual_seed(7 + rank)
@@ -389,19 +469,57 @@ def learning_and_evaluation(B, w, world, rank):
     hi = torch.tensor([dd["grids"][k].max() for k in range(ns)], dtype=torch.float64, device=device)
     vd = torch.tensor([dd["values_def"][k] for k in range(ns)], dtype=torch.float64, device=device)
     ss = (vd + (torch.rand((Qn, ns), dtype=torch.float64, device=device, generator=g) - 0.5) * 0.2 * (hi - lo)).clamp(lo, hi).contiguous()
-    one.rollout_shared(lagent, Qn, start_states=ss)
+    one.rollout_shared(eagent, Qn, start_states=ss)
     B.sync_all()
+    reps = 5
     t0 = time.perf_counter()
-    rsteps, rrew, rsucc, _ = one.rollout_shared(lagent, Qn, start_states=ss)
+    for _ in range(reps):
+        rsteps, rrew, rsucc, _ = one.rollout_shared(eagent, Qn, start_states=ss)
     B.sync_all()
-    edt = D.max_over_ranks(time.perf_counter() - t0, device)
+    edt = D.max_over_ranks(time.perf_counter() - t0, device) / reps
+    Rone = int(one.nrules[0].item())
     et = torch.tensor([float(rsteps.sum().item()), float((rsucc == 1).sum().item())], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(et)
-    eval_leg = {"value": et[0].item() / edt, "unit": "env-steps/s", "environments": Qn * world, "rules": int(one.nrules[0].item()),
-                "wall_s": edt, "env_steps": et[0].item(), "episodes_succeeded": et[1].item(),
-                "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates"}
-    return learn_leg, eval_leg
+    sweeps = et[0].item() + Qn * world                      # one greedy sweep per step + the first action's
+    # parity gate: sampled roll-outs replayed by the oracle's frirl_test_run episode on the same rule base (steps and reward exact)
+    gate = rollout_gate(one, eagent, env, ss, rsteps, rrew, [0, 1, Qn // 2, Qn - 1] + [int(i) for i in torch.topk(rsteps, 4).indices.tolist()])
+    legs["evaluation"] = {"value": et[0].item() / edt, "unit": "env-steps/s", "environments": Qn * world, "rules": Rone, "wall_s": edt, "env_steps": et[0].item(),
+                          "episodes_succeeded": et[1].item(), "longest_episode_rank0": int(rsteps.max().item()), "parity_gate": gate,
+                          "kernel": "rollout_resident_kernel (csrc/rollout.hip)" if frirl_amd.lib().frirl_hip_rollout_resident_rules(nant, A, 0, eagent.desc.env_kind) >= Rone else "rollout_shared_kernel",
+                          "fp64_issue": issue_record(sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)), edt,
+                                                     {"rule_visits": sweeps * Rone, "slots_per_visit": 14.4 * A + 2.0 * (nant - 1),
+                                                      "counted_from": "steps[] returned by the kernel: one greedy sweep over the rule base per step + one per episode start"}),
+                          "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates; average of 5 calls"}
+    return legs
+
+
+def rollout_gate(one, agent, env, ss, rsteps, rrew, sample):
+    """Sampled roll-outs against the oracle's frirl_test_run episode (portable trig) on the same rule base."""
+    import numpy as np
+    from oracle import binding as ob
+    nant = one.nant
+    R = int(one.nrules[0].item())
+    fr = ob.Frirl(env, trig_mode=1, maxR=max(1024, R + 8))
+    f = fr.five
+    while f.R:
+        assert ob.lib().orc_remove_rule(f.h, 0) == 0
+    u = one.u.cpu().numpy()
+    rb = one.rb[0].cpu().numpy()
+    # raw antecedents from the VE columns: every stored antecedent is a universe point (five_add_rule.c:76-81)
+    ve = one.ve.cpu().numpy()
+    for r in range(R):
+        rant = [u[k][int(np.nonzero(ve[k] == rb[k, r])[0][0])] for k in range(nant)]
+        assert f.add_rule(np.array(rant), rb[nant, r]) == 0
+    assert (f.veval[:, :R] == rb[:nant, :R]).all()
+    st, rw, s0 = rsteps.cpu().numpy(), rrew.cpu().numpy(), ss.cpu().numpy()
+    sample = sorted(set(sample))
+    for i in sample:
+        fr.set_start_state(s0[i])
+        fr.episode_eval()
+        assert st[i] == fr.ep_steps, f"roll-out {i}: {st[i]} steps, oracle {fr.ep_steps}"
+        assert abs(rw[i] - fr.ep_reward) <= 1e-9 * max(1.0, abs(fr.ep_reward)), f"roll-out {i}: reward {rw[i]}, oracle {fr.ep_reward}"
+    return {"checked": len(sample), "ok": True, "environments": sample, "what": "steps and total reward of whole roll-outs vs the oracle's frirl_test_run episode (longest episodes included)"}
 
 
 def main():
@@ -472,9 +590,9 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- legs 3 + 4 ----------------------------------------------------------------------------------------------
-    learn_leg = eval_leg = None
+    legs = None
     if w["env"] and not args.no_learn:
-        learn_leg, eval_leg = learning_and_evaluation(B, w, world, rank)
+        legs = learning_and_evaluation(B, w, world, rank)
         torch.cuda.empty_cache()
 
     # ---- the other BASELINE configurations, same two legs, shorter (N = 1 only: they are per-GPU workloads) -----------
@@ -514,10 +632,9 @@ def main():
         }
         if env_leg:
             out["env_steps"] = env_leg
-        if learn_leg:
-            out["learning"] = learn_leg
-        if eval_leg:
-            out["evaluation"] = eval_leg
+        out["parity_gate"] = val["parity_gate"]
+        if legs:
+            out.update(legs)
         if others:
             out["other_configs"] = others
         if not args.no_cpu_baseline and world == 1:

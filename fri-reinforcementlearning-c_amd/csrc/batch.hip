@@ -72,6 +72,7 @@ __global__ void count_running_kernel(const int32_t *__restrict__ done, int E, in
 extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
 {
     if (!b) return;
+    DeviceGuard keep_device_;
     (void)hipSetDevice(b->device);
     if (b->s) (void)hipStreamSynchronize(b->s);
     void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
@@ -86,6 +87,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
 {
     if (!d || !d->u || !d->ve || !d->agent.grid_values || !d->agent.action_ve || !d->rant0 || !d->rconc0) { set_error("frirl_hip_batch_create: NULL pointer"); return nullptr; }
     if (d->nant < 2 || d->nant > 9 || d->U < 2 || d->E < 1 || d->maxR < 2 || d->R0 < 1 || d->R0 > d->maxR || d->agent.A < 1 || d->agent.A > FRIRL_HIP_MAX_ACTIONS) { set_error("frirl_hip_batch_create: bad sizes"); return nullptr; }
+    DeviceGuard keep_device_;
     if (d->device_select == 1 && hipSetDevice(d->device) != hipSuccess) { set_error("frirl_hip_batch_create: hipSetDevice(%d) failed", d->device); (void)hipGetLastError(); return nullptr; }
     if (check_device()) return nullptr;
     frirl_hip_batch *b = new frirl_hip_batch();
@@ -139,7 +141,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
 extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
 {
     if (!b) { set_error("frirl_hip_batch_episode: NULL batch"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     int rc = frirl_hip_episode_begin(&b->t, &b->rb, &b->agent, &b->envs, b->s);
     if (rc) return rc;
     hipLaunchKernelGGL(frirl::mask_converged_kernel, dim3((b->E + 255) / 256), dim3(256), 0, b->s, b->d_done, b->d_converged, b->E);
@@ -190,7 +192,7 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
 extern "C" int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *episodes_run)
 {
     if (!b) { set_error("frirl_hip_batch_train: NULL batch"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     int ep = 0;
     for (ep = 1; ep < max_episodes; ep++) {             // at most max_episodes-1 episodes (frirl_sequential_run.c:51,59)
         int rc = frirl_hip_batch_episode(b);
@@ -205,10 +207,13 @@ extern "C" int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, i
     return FRIRL_HIP_OK;
 }
 
-extern "C" int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out)
+extern "C" int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out) { return frirl_host::batch_stats_first(b, out, nullptr); }
+
+// the same + "agent 0's rule base is complete" from the same download (the multi-device report's master flag)
+int frirl_host::batch_stats_first(frirl_hip_batch *b, frirl_hip_batch_stats_t *out, int32_t *first_converged)
 {
     if (!b || !out) { set_error("frirl_hip_batch_stats: NULL"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const int E = b->E;
     std::vector<double> rew(E);
     std::vector<int32_t> steps(E), nr(E), cv(E), eps(E);
@@ -229,13 +234,14 @@ extern "C" int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t
         if (eps[e] > out->episodes_max) out->episodes_max = eps[e];
     }
     out->total_env_steps = b->total_env_steps;
+    if (first_converged) *first_converged = cv[0];
     return FRIRL_HIP_OK;
 }
 
 extern "C" int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32_t *R, double *rant, double *rconc)
 {
     if (!b || !R || e < 0 || e >= b->E) { set_error("frirl_hip_batch_get_rulebase: bad arguments"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     int32_t r = 0;
     BCHK(hipMemcpy(&r, b->d_nrules + e, sizeof(int32_t), hipMemcpyDeviceToHost), "nrules download");
     *R = r;
@@ -253,7 +259,7 @@ extern "C" int frirl_hip_batch_get_rulebase(frirl_hip_batch *b, int32_t e, int32
 extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strategy, double reward_tolerance, int depth, frirl_hip_reduce_result *result)
 {
     if (!b || !result || e < 0 || e >= b->E) { set_error("frirl_hip_batch_reduce: bad arguments"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t n = b->nant, M = b->maxR;
     frirl_hip_rulebases one = b->rb;                                 // agent e's slab as a rule-base batch of one
     one.E = 1;
@@ -277,7 +283,7 @@ BatchView batch_view(frirl_hip_batch *b)
 
 int batch_merge_prepare(frirl_hip_batch *b, std::vector<int32_t> &conv)
 {
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t M = b->maxR, E = b->E;
     if (!b->d_weights) {
         if (!dalloc(&b->d_weights, E * M) || !dalloc(&b->d_active, E) || !dalloc(&b->d_full, E)) { set_error("frirl_hip_batch_merge_round: allocation failed"); return FRIRL_HIP_ELAUNCH; }
@@ -291,7 +297,7 @@ int batch_merge_prepare(frirl_hip_batch *b, std::vector<int32_t> &conv)
 
 int batch_merge_into_agents(frirl_hip_batch *b, const frirl_hip_sender *snd, bool skip_first)
 {
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t E = b->E;
     if (skip_first && E < 2) return FRIRL_HIP_OK;
     std::vector<uint8_t> act(E, 1);
@@ -305,7 +311,7 @@ int batch_merge_into_agents(frirl_hip_batch *b, const frirl_hip_sender *snd, boo
 
 int batch_merge_into_first(frirl_hip_batch *b, const frirl_hip_sender *snd)
 {
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     frirl_hip_rulebases master = b->rb;
     master.E = 1;
     return frirl_hip_merge_rb(&b->t, &master, &b->agent, b->d_rant, snd, b->d_weights, nullptr, b->d_full, b->s);
@@ -325,7 +331,7 @@ frirl_hip_sender batch_sender(frirl_hip_batch *b, int id)
 
 int batch_merge_finish(frirl_hip_batch *b, int32_t *full_agents)
 {
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t E = b->E;
     b->h_i.resize(E);
     BCHK(hipMemcpyAsync(b->h_i.data(), b->d_nrules, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "nrules download");
@@ -366,7 +372,7 @@ extern "C" int frirl_hip_batch_merge_round(frirl_hip_batch *b, int32_t *full_age
 extern "C" int frirl_hip_batch_train_merged(frirl_hip_batch *b, int32_t max_episodes, int32_t chunk, int32_t *episodes_run, int32_t *rounds)
 {
     if (!b || chunk < 2) { set_error("frirl_hip_batch_train_merged: bad arguments"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     int ep = 1, nrounds = 0;
     for (;;) {
         int32_t master_done = 0;
@@ -390,7 +396,7 @@ extern "C" int frirl_hip_batch_train_merged(frirl_hip_batch *b, int32_t max_epis
 extern "C" int frirl_hip_batch_save_rulebases(frirl_hip_batch *b, const char *path)
 {
     if (!b || !path) { set_error("frirl_hip_batch_save_rulebases: bad arguments"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t n = b->nant, M = b->maxR, E = b->E;
     std::vector<int32_t> nr(E);
     std::vector<double> rant(E * n * M), rb(E * (n + 1) * M);
@@ -419,7 +425,7 @@ extern "C" int frirl_hip_batch_save_rulebases(frirl_hip_batch *b, const char *pa
 extern "C" int frirl_hip_batch_load_rulebases(frirl_hip_batch *b, const char *path, int32_t *records_read)
 {
     if (!b || !path) { set_error("frirl_hip_batch_load_rulebases: bad arguments"); return FRIRL_HIP_EINVAL; }
-    BCHK(hipSetDevice(b->device), "hipSetDevice");
+    DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t n = b->nant, M = b->maxR, E = b->E;
     FILE *fp = fopen(path, "rb");
     if (!fp) { set_error("frirl_hip_batch_load_rulebases: cannot open %s", path); return FRIRL_HIP_EINVAL; }

@@ -18,6 +18,8 @@ struct BatchView {                 // what the multi-device exchange needs to se
     int32_t *d_nrules, *d_converged;
 };
 BatchView batch_view(frirl_hip_batch *b);
+// frirl_hip_batch_stats + whether agent 0 of the batch has converged (NULL: not wanted)
+int batch_stats_first(frirl_hip_batch *b, frirl_hip_batch_stats_t *out, int32_t *first_converged);
 
 // start of a merge round: the receivers' FIVERB.weights as learning left them (frirl_hip_weights_from_spread); conv = the agents'
 // "rule base complete" flags (host copy)

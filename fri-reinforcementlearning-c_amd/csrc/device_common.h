@@ -139,6 +139,15 @@ int check_tables(const frirl_hip_tables *t);
 int check_rulebases(const frirl_hip_tables *t, const frirl_hip_rulebases *b);
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// The library-owned batches switch to their own device; the caller's current device is put back on every exit path.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // Experiment / test switches (frirl_hip_set_option).  Defaults (0 / -1 = the shipped configuration) are read ONCE from
 // the FRIRL_HIP_* environment variables when the library first needs them, never per launch.
 struct Options {
@@ -159,6 +168,7 @@ struct Options {
     int rollout_wps;      // resident roll-out: persistent waves per SIMD, 1 or 2 (0 = 2)             (FRIRL_HIP_ROLLOUT_WPS)
     int learn_slices;     // persistent learner: lanes per agent 4 / 16 / 64, 0 = by the number of live agents (FRIRL_HIP_LEARN_SLICES)
     int learn_persistent; // 0: frirl_hip_learn_supported answers no (callers fall back to one episode per launch) (FRIRL_HIP_LEARN_PERSISTENT)
+    int multi_loopback;   // 1: frirl_hip_multi_create builds LOGICAL shards on the current device with the loop-back transport (tests) (FRIRL_HIP_MULTI_LOOPBACK)
     int mirror_sync;      // single-agent fused step: 1 = wait with hipStreamSynchronize instead of polling the completion flag (FRIRL_HIP_MIRROR_SYNC)
     int no_many;          // 9..24 actions: 1 = action-parallel waves (sweep_gba_wide) instead of all actions in registers (FRIRL_HIP_NO_MANY)
 };

@@ -1,0 +1,540 @@
+#pragma once
+// learn_kernel.h -- the construct loop of frirl_sequential_run (reference src/frirl/frirl_sequential_run.c:55-165: episodes until the
+// rule base is "considered complete") for MANY agents with small rule bases, as ONE persistent launch per chunk of work: every
+// agent runs episode after episode at its own pace -- frirl_episode's loop (frirl_episode.c:28-194), the SARSA update
+// (frirl_update_sarsa.c:22-143,348-385), and at each episode's end the loop's own bookkeeping (:68-72,83-148) -- until it has
+// converged, has used its step budget for this launch, or has run max_episodes - 1 episodes.
+//
+// Why not one episode per launch (lanes.hip): agents of a real many-agent run (start states diversified per agent, reference
+// frirl_agent.c:121-139) are never in step -- at any moment some are still in their 1000-step failing episodes while others
+// finish in 80 steps, and they converge after anything between 300 and 30 000 steps.  A launch that waits for the longest
+// episode of the batch idles most lanes most of the time.  Here nothing waits: the launch ends when every agent has spent its
+// budget, and between launches the host compacts the agents that are still learning (`live` list) and gives them more lanes
+// each (H) as their number shrinks.
+//
+// Mapping: a GROUP of H consecutive lanes owns one agent; lane h holds the rules r = h (mod H) and evaluates ALL A + 1
+// conclusions of a step for them -- Q(s', a) for every action (state part of the squared distance once per rule) and Q(s, a) of
+// the pending update -- so nothing is computed twice inside a group except the environment's own dynamics; the H partial sums
+// are combined by a butterfly.  Rule bases live in per-wave tiles T[tile][j][lane] (rule r = j H + h of the lane's agent):
+// every load of the sweep is one contiguous 64-lane run.  A rule is a packed record of BITS-bit universe indices (4 B for the
+// 41-point universes of mountaincar / acrobot, 8 B for cartpole's 1001 points) + its consequent; VE values are gathered from an
+// LDS copy of the tables (rb[e][k][r] == ve[k][uidx[e][k][r]] exactly, five_add_rule.c:76-81): 12 B per rule and step from
+// HBM / L2 instead of 48.  Rules are walked from the highest index down so that "the lowest exact hit" is simply the last one
+// seen.  Sums: per lane in (descending) index order, slices added in butterfly order -- interpolated values, <= 1e-6 contract.
+#include "sweeps.h"
+#include "envs.h"
+#include <type_traits>
+
+namespace frirl {
+
+#ifndef LEARN_UR
+#define LEARN_UR 2      // rules fetched per batch, two batches in flight
+#endif
+constexpr int LR_BLOCK = 256;
+constexpr int LR_WPB = LR_BLOCK / FRIRL_WAVE;
+
+struct LearnArgs {
+    const double *u, *ve;        // tables [nant][U]
+    int U;
+    uint32_t *Ti;                // [tiles][njmax][64][W] packed universe indices
+    double *Tq;                  // [tiles][njmax][64]    consequents
+    double *Tp;                  // [tiles][njmax][64]    consequents after the previous episode (frirl_sequential_run.c:72)
+    const int32_t *live;         // [nlive] agents of this launch, or NULL = 0..nlive-1
+    int nlive, tiles, njmax;
+    double *rb;                  // canonical slabs: VE columns of appended rules are written through
+    uint16_t *uidx;
+    int32_t *nrules;
+    int maxR;
+    int64_t *work;               // [E][2] rule visits of the main sweeps / of the extra sweeps (snapped point, weighted spread), or NULL
+    int64_t *steps_total;        // [E] environment steps so far, or NULL
+    int budget;                  // environment steps per agent in this launch
+    int max_episodes;            // the loop runs episodes 1 .. max_episodes - 1 (frirl_sequential_run.c:51,59)
+};
+
+template <int BITS>
+struct Packed {
+    static constexpr int FPW = 32 / BITS;                       // fields per 32-bit word
+    static constexpr int words(int nant) { return (nant + FPW - 1) / FPW; }
+};
+
+// ---- import / export: canonical rb[e][nant][r], uidx[e][k][r], prev_rconc[e][r]  <->  tiles --------------------------------
+template <int NANT, int BITS>
+__global__ __launch_bounds__(256) void learn_import_kernel(const LearnArgs la, int H, const double *__restrict__ prev_rconc)
+{
+    constexpr int FPW = Packed<BITS>::FPW, W = Packed<BITS>::words(NANT);
+    const int tile = blockIdx.x, EPW = FRIRL_WAVE / H;
+    const int lane = threadIdx.x & 63, il = lane / H, h = lane % H;
+    const int slot = tile * EPW + il;
+    const bool exists = slot < la.nlive;
+    const int e = exists ? (la.live ? la.live[slot] : slot) : 0;
+    const int R = exists ? la.nrules[e] : 0;
+    const int nj = (R + H - 1) / H;
+    int njw = nj;                                               // rounds needed by any agent of the tile
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(njw, off, FRIRL_WAVE); njw = o > njw ? o : njw; }
+    for (int j = threadIdx.x / 64; j < njw; j += 4) {
+        const int r = j * H + h;
+        uint32_t w[W];
+#pragma unroll
+        for (int x = 0; x < W; x++) w[x] = 0u;
+        double q = 0.0, p = 0.0;
+        if (r < R) {
+#pragma unroll
+            for (int k = 0; k < NANT; k++) w[k / FPW] |= (uint32_t)la.uidx[((size_t)e * NANT + k) * la.maxR + r] << (BITS * (k % FPW));
+            q = la.rb[((size_t)e * (NANT + 1) + NANT) * la.maxR + r];
+            p = prev_rconc[(size_t)e * la.maxR + r];
+        }
+        const size_t o = ((size_t)tile * la.njmax + j) * 64 + lane;
+#pragma unroll
+        for (int x = 0; x < W; x++) la.Ti[o * W + x] = w[x];
+        la.Tq[o] = q;
+        la.Tp[o] = p;
+    }
+}
+
+template <int NANT>
+__global__ __launch_bounds__(256) void learn_export_kernel(const LearnArgs la, int H, double *__restrict__ prev_rconc)
+{
+    constexpr int nant = NANT;
+    const int tile = blockIdx.x, EPW = FRIRL_WAVE / H;
+    const int lane = threadIdx.x & 63, il = lane / H, h = lane % H;
+    const int slot = tile * EPW + il;
+    const bool exists = slot < la.nlive;
+    const int e = exists ? (la.live ? la.live[slot] : slot) : 0;
+    const int R = exists ? la.nrules[e] : 0;
+    const int nj = (R + H - 1) / H;
+    int njw = nj;
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(njw, off, FRIRL_WAVE); njw = o > njw ? o : njw; }
+    for (int j = threadIdx.x / 64; j < njw; j += 4) {
+        const int r = j * H + h;
+        if (r < R) {
+            const size_t o = ((size_t)tile * la.njmax + j) * 64 + lane;
+            la.rb[((size_t)e * (nant + 1) + nant) * la.maxR + r] = la.Tq[o];
+            prev_rconc[(size_t)e * la.maxR + r] = la.Tp[o];
+        }
+    }
+}
+
+// ---- the learner ------------------------------------------------------------------------------------------------------
+template <int NANT, int NA, int KIND, int H, int BITS, int WPS>
+__global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la, const frirl_hip_agent ag, const frirl_hip_envs ev,
+                                                              const frirl_hip_convergence cv)
+{
+    constexpr int NS = NANT - 1, EPW = FRIRL_WAVE / H, NC = NA + 1;           // NC conclusions per step: A actions at s', Q(s, a)
+    constexpr int FPW = Packed<BITS>::FPW, W = Packed<BITS>::words(NANT);
+    constexpr int UR = LEARN_UR;                                        // rules fetched per batch, two batches in flight
+    using RecI = typename std::conditional<W == 1, uint32_t, typename std::conditional<W == 2, uint2, uint4>::type>::type;
+    extern __shared__ double tab_s[];                                         // [NANT][U] VE tables, then [NANT][U] universes (if lds_u)
+    __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
+    __shared__ double udiv[NANT];                                             // FIVEInit.c:244-248, once instead of per observation
+    // cold per-agent state, parked here for the duration of every sweep (see below): 2 NS + 2 NANT + 3 doubles and 8 words per group
+    constexpr int NCOLD = 2 * NS + 2 * NANT + 3 + 4;
+    __shared__ double cold_s[LR_WPB * (FRIRL_WAVE / H) * NCOLD];
+    const int U = la.U, maxR = la.maxR;
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
+    const int il = lane / H, h = lane % H;
+    const int tile = blockIdx.x * LR_WPB + wave;
+    const int slot = tile * EPW + il;
+    const bool exists = tile < la.tiles && slot < la.nlive;
+    const int e = exists ? (la.live ? la.live[slot] : slot) : 0;
+    for (int i = threadIdx.x; i < NANT * U; i += LR_BLOCK) tab_s[i] = la.ve[i];
+    constexpr bool LU = KIND != FRIRL_HIP_ENV_CARTPOLE;                          // small tables: the universes in LDS too
+    if (LU) for (int i = threadIdx.x; i < NANT * U; i += LR_BLOCK) tab_s[NANT * U + i] = la.u[i];
+    for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += LR_BLOCK) grid_s[i] = ag.grid_values[i];
+    __syncthreads();
+    const double *ves = tab_s, *us;
+    if constexpr (LU) us = tab_s + NANT * U; else us = la.u;
+    if ((int)threadIdx.x < NANT) udiv[threadIdx.x] = universe_div(us + (size_t)threadIdx.x * U, U);
+    __syncthreads();
+    auto observe = [&](int k, double x) { const double *uni = us + (size_t)k * U; return ves[(size_t)k * U + snap_index(uni, U, x, udiv[k])]; };
+    const size_t tbase = (size_t)(tile < la.tiles ? tile : 0) * la.njmax * 64;
+    const RecI *Ti_l = reinterpret_cast<const RecI *>(la.Ti) + tbase + lane;      // this lane's rules: element j at [j * 64]
+    double *Tq_l = la.Tq + tbase + lane, *Tp_l = la.Tp + tbase + lane;
+    RecI *Ti_g = reinterpret_cast<RecI *>(la.Ti) + tbase + il * H;                // the group's rule r: [(r / H) * 64 + r % H]
+    double *Tq_g = la.Tq + tbase + il * H;
+    const auto pk = pin_pow(PowC<NANT>());
+    double ave[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) ave[a] = ag.action_ve[a];
+
+    auto decode = [&](const RecI &x, double (&c)[NANT]) {
+        uint32_t w[W];
+        if constexpr (W == 1) { w[0] = x; } else if constexpr (W == 2) { w[0] = x.x; w[1] = x.y; } else { w[0] = x.x; w[1] = x.y; w[2] = x.z; if constexpr (W > 3) w[3] = x.w; }
+#pragma unroll
+        for (int k = 0; k < NANT; k++) {
+            const uint32_t idx = (w[k / FPW] >> (BITS * (k % FPW))) & ((1u << BITS) - 1u);
+            c[k] = ves[k * U + (int)idx];
+        }
+    };
+    // f(r, VE values of rule r, its consequent) for this lane's rules r = j H + h < R, from the highest j down; NEEDQ: load consequents
+    auto for_slice = [&](int R, bool needq, auto &&f) {
+        const int nj = (R - h + H - 1) / H;                                   // this lane's rules: j = 0 .. nj - 1
+        if (nj <= 0) return;
+        RecI ia[UR], ib[UR];
+        double qa[UR], qb[UR];
+        auto fetch = [&](RecI(&xi)[UR], double(&xq)[UR], int jtop) {        // rules jtop, jtop - 1, ..., jtop - UR + 1 (clamped at 0)
+#pragma unroll
+            for (int t = 0; t < UR; t++) {
+                const int j = jtop - t < 0 ? 0 : jtop - t;
+                xi[t] = Ti_l[(size_t)j * 64];
+                xq[t] = needq ? Tq_l[(size_t)j * 64] : 0.0;
+            }
+        };
+        auto consume = [&](const RecI(&xi)[UR], const double(&xq)[UR], int jtop) {
+#pragma unroll
+            for (int t = 0; t < UR; t++) {
+                const int j = jtop - t;
+                if (j >= 0) { double c[NANT]; decode(xi[t], c); f(j * H + h, c, xq[t]); }
+            }
+        };
+        int jt = nj - 1;
+        fetch(ia, qa, jt);
+        while (jt >= 0) {
+            fetch(ib, qb, jt - UR);
+            consume(ia, qa, jt);
+            fetch(ia, qa, jt - 2 * UR);
+            consume(ib, qb, jt - UR);
+            jt -= 2 * UR;
+        }
+    };
+    auto group_or = [&](bool v) -> bool {
+        const unsigned long long b = __ballot(v ? 1 : 0);
+        if constexpr (H == 64) return b != 0ull;
+        else return ((b >> (il * H)) & ((1ull << H) - 1ull)) != 0ull;
+    };
+
+    // ---- per-agent state (replicated in the H lanes of the group) ----------------------------------------------------------
+    double states[NS], q_ant[NANT], total = 0.0, prev_reward = 0.0;
+    int R = 0, fus = 0, steps = 0, prevR = 0, prev_steps = 0, nep = 0, lsteps = 0;
+    bool active = false, begin = false, converged = false, refused = false;
+    uint32_t episode = 0;
+    long long wmain = 0, wextra = 0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) states[k] = exists ? ev.states[(size_t)e * NS + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NANT; k++) q_ant[k] = exists ? ev.q_ant[(size_t)e * NANT + k] : 0.0;
+    if (exists) {
+        R = la.nrules[e]; fus = ev.fus[e]; steps = ev.ep_steps[e]; total = ev.ep_reward[e];
+        begin = ev.done[e] != 0;                                              // between two episodes: start the next one
+        episode = ev.episode ? (uint32_t)ev.episode[e] : 0u;
+        prevR = cv.prev_nrules[e]; prev_steps = cv.prev_steps[e]; prev_reward = cv.prev_reward[e];
+        converged = cv.converged[e] != 0; nep = cv.episodes[e];
+        active = !converged && nep < la.max_episodes - 1 && la.budget > 0;
+    }
+
+    while (__any(active ? 1 : 0)) {
+        double cur[NS], cur_q[NANT], ve1[NANT], ve2[NS], reward = 0.0;
+        int success = 0;
+        if (active) {
+            if (begin) {                                                      // frirl_episode.c:46-48: q_states = states = start state
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    const double v = ev.start_states ? ev.start_states[(size_t)e * NS + k] : ag.values_def[k];
+                    states[k] = v; cur[k] = v; cur_q[k] = v; q_ant[k] = v;
+                }
+                steps = 0; total = 0.0;
+            } else {
+                env_do_action(KIND, q_ant[NS], states, cur);                                     // :97
+                env_get_reward(KIND, cur, reward, success);                                      // :106
+                env_quantize(KIND, NS, grid_s, ag.grid_len, ag.grid_div, cur, cur_q);            // :112
+            }
+#pragma unroll
+            for (int k = 0; k < NANT; k++) ve1[k] = observe(k, q_ant[k]);
+#pragma unroll
+            for (int k = 0; k < NS; k++) ve2[k] = observe(k, cur_q[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NANT; k++) ve1[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; k++) { ve2[k] = 0.0; cur[k] = 0.0; cur_q[k] = 0.0; }
+        }
+
+        // ---- the agent's cold state leaves the registers for the duration of the sweep: it is the same in all H lanes of the group,
+        //      so lane 0 parks it in LDS and every lane reads it back afterwards (the compiler may not forward across the fences);
+        //      without this the kernel needs > 256 VGPRs and spills to scratch inside the rule loop
+        double *cold = cold_s + (size_t)(wave * EPW + il) * NCOLD;
+        if (h == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; k++) { cold[k] = states[k]; cold[NS + k] = cur[k]; }
+#pragma unroll
+            for (int k = 0; k < NANT; k++) { cold[2 * NS + k] = q_ant[k]; cold[2 * NS + NANT + k] = cur_q[k]; }
+            cold[2 * NS + 2 * NANT] = total; cold[2 * NS + 2 * NANT + 1] = prev_reward; cold[2 * NS + 2 * NANT + 2] = reward;
+            int *ci = reinterpret_cast<int *>(cold + 2 * NS + 2 * NANT + 3);
+            ci[0] = fus; ci[1] = steps; ci[2] = prevR; ci[3] = prev_steps; ci[4] = nep; ci[5] = lsteps; ci[6] = (int)episode; ci[7] = success;
+        }
+        asm volatile("" ::: "memory");
+
+        // ---- one pass over this lane's rules: Q(s', a) for every action (frirl_get_best_action, :148) and Q(s, a) of the pending
+        //      update (frirl_update_sarsa.c:357); an exact hit poisons the sums of its own conclusion, which are then not read
+        double sv[NC], sw[NC];
+        unsigned sh[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) { sv[i] = 0.0; sw[i] = 0.0; sh[i] = FRIRL_HIP_NO_HIT; }
+        if (active) {
+            for_slice(R, true, [&](int r, const double (&c)[NANT], double cq) {
+                const double e0 = ve2[0] - c[0], g0 = ve1[0] - c[0];
+                double s2 = e0 * e0, s1 = g0 * g0;
+#pragma unroll
+                for (int k = 1; k < NS; k++) {
+                    const double d2 = ve2[k] - c[k], d1 = ve1[k] - c[k];
+                    s2 = __fma_rn(d2, d2, s2);
+                    s1 = __fma_rn(d1, d1, s1);
+                }
+                const double va = c[NS];
+#pragma unroll
+                for (int a = 0; a < NA; a++) {
+                    const double ea = ave[a] - va;
+                    const double d = __fma_rn(ea, ea, s2);
+                    sh[a] = (d == 0.0) ? (unsigned)r : sh[a];                 // descending walk: the last hit seen is the lowest
+                    const double wi = shepard_w(d, pk);
+                    sv[a] = __fma_rn(wi, cq, sv[a]);
+                    sw[a] = sw[a] + wi;
+                }
+                const double e1 = ve1[NS] - va;
+                const double d = __fma_rn(e1, e1, s1);
+                sh[NA] = (d == 0.0) ? (unsigned)r : sh[NA];
+                const double wi = shepard_w(d, pk);
+                sv[NA] = __fma_rn(wi, cq, sv[NA]);
+                sw[NA] = sw[NA] + wi;
+            });
+            wmain += R;
+        }
+        if (H > 1) {                                                          // the H rule slices of every conclusion, a few conclusions at a time
+            constexpr int CH = 4;
+#pragma unroll
+            for (int i0 = 0; i0 < NC; i0 += CH) {
+                for (int off = 1; off < H; off <<= 1) {
+                    double tv[CH], tw[CH];
+                    unsigned th[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; i++) if (i0 + i < NC) { tv[i] = __shfl_xor(sv[i0 + i], off, FRIRL_WAVE); tw[i] = __shfl_xor(sw[i0 + i], off, FRIRL_WAVE); th[i] = (unsigned)__shfl_xor((int)sh[i0 + i], off, FRIRL_WAVE); }
+#pragma unroll
+                    for (int i = 0; i < CH; i++) if (i0 + i < NC) { sv[i0 + i] = sv[i0 + i] + tv[i]; sw[i0 + i] = sw[i0 + i] + tw[i]; sh[i0 + i] = th[i] < sh[i0 + i] ? th[i] : sh[i0 + i]; }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        {
+#pragma unroll
+            for (int k = 0; k < NS; k++) { states[k] = cold[k]; cur[k] = cold[NS + k]; }
+#pragma unroll
+            for (int k = 0; k < NANT; k++) { q_ant[k] = cold[2 * NS + k]; cur_q[k] = cold[2 * NS + NANT + k]; }
+            total = cold[2 * NS + 2 * NANT]; prev_reward = cold[2 * NS + 2 * NANT + 1]; reward = cold[2 * NS + 2 * NANT + 2];
+            const int *ci = reinterpret_cast<const int *>(cold + 2 * NS + 2 * NANT + 3);
+            fus = ci[0]; steps = ci[1]; prevR = ci[2]; prev_steps = ci[3]; nep = ci[4]; lsteps = ci[5]; episode = (uint32_t)ci[6]; success = ci[7];
+        }
+        if (active) {
+            // greedy action: first maximum in action order (max.inl:21)
+            double bv = 0.0;
+            int ci = 0;
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                const double c = (sh[a] != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(sh[a] / H) * 64 + (sh[a] % H)] : sv[a] / sw[a];
+                if (a == 0 || bv < c) { bv = c; ci = a; }
+            }
+            if (begin) {
+                episode++;
+                const int a0 = e_greedy(ag, ci, (uint32_t)e, episode, 0u);                              // :78-82
+                q_ant[NS] = grid_s[NS * FRIRL_HIP_MAX_GRID + a0];
+                begin = false;
+            } else {
+                const int chosen = e_greedy(ag, ci, (uint32_t)e, episode, (uint32_t)steps + 1u);
+                double qp = bv;                                                                          // Q(s',a'), frirl_update_sarsa.c:356
+                if (chosen != ci) {                                                                      // an exploratory action: its own conclusion
+                    double v = sv[0], w = sw[0];
+                    unsigned hh = sh[0];
+#pragma unroll
+                    for (int a = 1; a < NA; a++) { v = (a == chosen) ? sv[a] : v; w = (a == chosen) ? sw[a] : w; hh = (a == chosen) ? sh[a] : hh; }
+                    qp = (hh != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(hh / H) * 64 + (hh % H)] : v / w;
+                }
+                const unsigned hit1 = sh[NA];
+                const double vs1 = sv[NA], ws1 = sw[NA];
+                const double qnow = (hit1 != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(hit1 / H) * 64 + (hit1 % H)] : vs1 / ws1;   // Q(s,a), :357
+                cur_q[NS] = grid_s[NS * FRIRL_HIP_MAX_GRID + chosen];                                    // frirl_episode.c:151
+
+                // ---- frirl_update_sarsa + update_rules (frirl_update_sarsa.c:348-385, :22-143): every lane of the group follows the
+                //      same branch; single stores are issued by lane 0, the weighted spread by every lane for its own rules
+                if (!ag.evaluate) {                                                                     // frirl_episode.c:155
+                    const double qdiff = ag.alpha * (reward + ag.gamma * qp - qnow);                    // :358
+                    bool finished = false;
+                    if (qdiff > ag.qdiff_pos_boundary || qdiff < ag.qdiff_neg_boundary) {               // :363
+                        double rant[NANT], ve3[NANT];
+                        unsigned idx3[NANT];
+                        bool same = true;
+#pragma unroll
+                        for (int k = 0; k < NANT; k++) {
+                            rant[k] = check_possible_states(q_ant[k], grid_s + k * FRIRL_HIP_MAX_GRID, ag.grid_len[k]);   // :146-170
+                            const double *uni = us + (size_t)k * U;
+                            idx3[k] = snap_index(uni, U, rant[k], udiv[k]);
+                            ve3[k] = ves[(size_t)k * U + idx3[k]];
+                            same = same && (ve3[k] == ve1[k]);
+                        }
+                        double v3 = vs1, w3 = ws1;                                                      // :370 (same VE point => same sums)
+                        unsigned hit3 = hit1;
+                        if (!same) {
+                            v3 = 0.0; w3 = 0.0; hit3 = FRIRL_HIP_NO_HIT;
+                            for_slice(R, true, [&](int r, const double (&c)[NANT], double cq) {
+                                const double d0 = ve3[0] - c[0];
+                                double s = d0 * d0;
+#pragma unroll
+                                for (int k = 1; k < NANT; k++) { const double d = ve3[k] - c[k]; s = __fma_rn(d, d, s); }
+                                hit3 = (s == 0.0) ? (unsigned)r : hit3;
+                                const double wi = shepard_w(s, pk);
+                                v3 = __fma_rn(wi, cq, v3);
+                                w3 = w3 + wi;
+                            });
+                            for (int off = 1; off < H; off <<= 1) {
+                                const double tv = __shfl_xor(v3, off, FRIRL_WAVE), tw = __shfl_xor(w3, off, FRIRL_WAVE);
+                                const unsigned th = (unsigned)__shfl_xor((int)hit3, off, FRIRL_WAVE);
+                                v3 = v3 + tv; w3 = w3 + tw; hit3 = th < hit3 ? th : hit3;
+                            }
+                            wextra += R;
+                        }
+                        if (hit3 == FRIRL_HIP_NO_HIT) {                                                 // :373-377 append and leave
+                            if (R >= maxR) {
+                                refused = true;
+                            } else {
+                                if (h == 0) {
+                                    uint32_t w[W];
+#pragma unroll
+                                    for (int x = 0; x < W; x++) w[x] = 0u;
+#pragma unroll
+                                    for (int k = 0; k < NANT; k++) w[k / FPW] |= (idx3[k] & ((1u << BITS) - 1u)) << (BITS * (k % FPW));
+                                    RecI x;
+                                    if constexpr (W == 1) { x = w[0]; } else if constexpr (W == 2) { x.x = w[0]; x.y = w[1]; } else { x.x = w[0]; x.y = w[1]; x.z = w[2]; x.w = W > 3 ? w[W - 1] : 0u; }
+                                    const size_t o = (size_t)(R / H) * 64 + (R % H);
+                                    Ti_g[o] = x;
+                                    Tq_g[o] = v3 / w3 + qdiff;
+#pragma unroll
+                                    for (int k = 0; k < NANT; k++) {
+                                        la.rb[((size_t)e * (NANT + 1) + k) * maxR + R] = ve3[k];        // five_add_rule.c:80-81 (canonical slab)
+                                        la.uidx[((size_t)e * NANT + k) * maxR + R] = (uint16_t)idx3[k];  // :76
+                                        if (ev.rant) ev.rant[((size_t)e * NANT + k) * maxR + R] = rant[k];
+                                    }
+                                }
+                                R++;
+                                fus = 1;
+                            }
+                            finished = true;
+                        } else {
+                            fus = 0;                                                                    // :378
+                        }
+                    }
+                    if (!finished) {
+                        const int rules = fus ? R - 1 : R;                                              // :30-33
+                        if (hit1 != FRIRL_HIP_NO_HIT && (ag.skip_rules == 0 || (ag.skip_rules == 1 && (int)hit1 < rules))) {
+                            if (h == 0) Tq_g[(size_t)(hit1 / H) * 64 + (hit1 % H)] = qnow + qdiff;       // :55
+                        } else if (ag.skip_rules == 1 && hit1 != FRIRL_HIP_NO_HIT && (int)hit1 == rules) {
+                            // :61-63 hit on the just-inserted rule: skipped
+                        } else {
+                            if (ag.skip_rules == 0) fus = 0;                                            // :70-73
+                            const int r_skip = fus ? R - 1 : -1;                                        // :76,124-126
+                            if (hit1 == FRIRL_HIP_NO_HIT && h == 0 && ev.spread_ant) {   // this call defines FIVERB.weights from now on (frirl_hip.h)
+#pragma unroll
+                                for (int k = 0; k < NANT; k++) ev.spread_ant[(size_t)e * NANT + k] = q_ant[k];
+                                if (ev.spread_R) ev.spread_R[e] = R;
+                            }
+                            const double iws = 1.0 / ws1;
+                            for_slice(R, false, [&](int r, const double (&c)[NANT], double) {           // K6 + K7, every lane its own rules
+                                const double d0 = ve1[0] - c[0];
+                                double s = d0 * d0;
+#pragma unroll
+                                for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; s = __fma_rn(d, d, s); }
+                                const double w = shepard_w(s, pk) * iws;
+                                if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; Tq_l[(size_t)(r / H) * 64] = qnow + t; }
+                            });
+                            wextra += R;
+                        }
+                    }
+                    __threadfence_block();          // the group's stores are visible to its other lanes before the next sweep
+                }
+#pragma unroll
+                for (int k = 0; k < NS; k++) { states[k] = cur[k]; q_ant[k] = cur_q[k]; }               // :163-168
+                q_ant[NS] = cur_q[NS];
+                steps++;                                                                                // :174
+                lsteps++;
+                total = total + reward;                                                                 // :107
+                if (success == 1 || steps >= ag.max_steps) {                                            // :183, :86 -- the episode is over
+                    // frirl_sequential_run.c:83-148: "RB considered complete" = same #rules, #steps and (good) reward as the previous
+                    // episode and no consequent moved by the tolerance or more; then the loop's snapshot (:68-72)
+                    const bool same = prevR == R && prev_steps == steps && total > ag.reward_good_above && prev_reward == total;
+                    bool moved = false;
+                    const int nj = (R - h + H - 1) / H;
+                    for (int j = 0; j < nj; j++) {
+                        const double q = Tq_l[(size_t)j * 64];
+                        if (same && fabs(q - Tp_l[(size_t)j * 64]) >= ag.qdiff_final_tolerance) moved = true;
+                        Tp_l[(size_t)j * 64] = q;
+                    }
+                    moved = group_or(moved);
+                    nep++;
+                    if (same && !moved) converged = true;
+                    prevR = R; prev_steps = steps; prev_reward = total;
+                    begin = true;
+                    if (converged || nep >= la.max_episodes - 1) active = false;
+                }
+                if (lsteps >= la.budget) active = false;
+            }
+        }
+    }
+
+    if (!exists || h != 0) return;
+#pragma unroll
+    for (int k = 0; k < NS; k++) ev.states[(size_t)e * NS + k] = states[k];
+#pragma unroll
+    for (int k = 0; k < NANT; k++) ev.q_ant[(size_t)e * NANT + k] = q_ant[k];
+    ev.fus[e] = fus;
+    ev.ep_steps[e] = steps;
+    ev.ep_reward[e] = total;
+    ev.done[e] = begin ? 1 : 0;
+    if (ev.episode) ev.episode[e] = (int32_t)episode;
+    if (ev.status) ev.status[e] = refused ? FRIRL_HIP_UPD_FULL : FRIRL_HIP_UPD_INACTIVE;
+    la.nrules[e] = R;
+    cv.prev_nrules[e] = prevR; cv.prev_steps[e] = prev_steps; cv.prev_reward[e] = prev_reward;
+    cv.converged[e] = converged ? 1 : 0; cv.episodes[e] = nep;
+    if (la.work) { la.work[2 * (size_t)e] += wmain; la.work[2 * (size_t)e + 1] += wextra; }
+    if (la.steps_total) la.steps_total[e] += lsteps;
+}
+
+}  // namespace frirl
+
+
+template <int N, int NA, int KIND, int H, int BITS, int WPS>
+inline void launch_learn(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                         const frirl_hip_convergence *cv, frirl::LearnArgs la, hipStream_t s)
+{
+    constexpr int EPW = FRIRL_WAVE / H, W = frirl::Packed<BITS>::words(N);
+    la.tiles = (la.nlive + EPW - 1) / EPW;
+    la.njmax = (b->maxR + H - 1) / H;
+    const size_t n = (size_t)la.tiles * la.njmax * 64;
+    char *ws = reinterpret_cast<char *>(la.Ti);
+    la.Tq = reinterpret_cast<double *>(ws + ((n * W * sizeof(uint32_t) + 15) / 16) * 16);
+    la.Tp = la.Tq + n;
+    const size_t tab = sizeof(double) * N * (size_t)t->U;
+    const size_t dyn = tab + (KIND != FRIRL_HIP_ENV_CARTPOLE ? tab : 0);
+    hipLaunchKernelGGL((frirl::learn_import_kernel<N, BITS>), dim3(la.tiles), dim3(256), 0, s, la, H, cv->prev_rconc);
+    const int blocks = (la.tiles + frirl::LR_WPB - 1) / frirl::LR_WPB;
+    hipLaunchKernelGGL((frirl::learn_kernel<N, NA, KIND, H, BITS, WPS>), dim3(blocks), dim3(frirl::LR_BLOCK), dyn, s, la, *ag, *ev, *cv);
+    hipLaunchKernelGGL((frirl::learn_export_kernel<N>), dim3(la.tiles), dim3(256), 0, s, la, H, cv->prev_rconc);
+}
+
+
+// one environment's launcher for the lane-group sizes [HLO, HHI]: each instantiation file (learn_i*.hip) compiles a few kernels, so
+// that the build runs them in parallel
+template <int N, int NA, int KIND, int BITS, int WPS, int HLO, int HHI>
+inline void launch_learn_h(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                           const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s)
+{
+    if constexpr (HLO <= 2 && 2 <= HHI) if (H == 2) return launch_learn<N, NA, KIND, 2, BITS, WPS>(t, b, ag, ev, cv, la, s);
+    if constexpr (HLO <= 4 && 4 <= HHI) if (H == 4) return launch_learn<N, NA, KIND, 4, BITS, WPS>(t, b, ag, ev, cv, la, s);
+    if constexpr (HLO <= 8 && 8 <= HHI) if (H == 8) return launch_learn<N, NA, KIND, 8, BITS, WPS>(t, b, ag, ev, cv, la, s);
+    if constexpr (HLO <= 16 && 16 <= HHI) if (H == 16) return launch_learn<N, NA, KIND, 16, BITS, WPS>(t, b, ag, ev, cv, la, s);
+    if constexpr (HLO <= 32 && 32 <= HHI) if (H == 32) return launch_learn<N, NA, KIND, 32, BITS, WPS>(t, b, ag, ev, cv, la, s);
+    if constexpr (HLO <= 64 && 64 <= HHI) if (H == 64) return launch_learn<N, NA, KIND, 64, BITS, WPS>(t, b, ag, ev, cv, la, s);
+}
+
+// defined in learn_i0.hip (mountaincar), learn_i1.hip (acrobot, 2 .. 8 lanes per agent), learn_i2.hip (acrobot, 16 .. 64)
+void frirl_learn_launch_mountaincar(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                                    const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s);
+void frirl_learn_launch_acrobot_lo(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                                   const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s);
+void frirl_learn_launch_acrobot_hi(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                                   const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s);

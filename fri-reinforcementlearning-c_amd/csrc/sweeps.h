@@ -424,8 +424,8 @@ __device__ QResult sweep_q(const COLS &cols, const double *__restrict__ qcol, in
         if (!TRACK || r < R) {
             double a0, a1;
             sq_dist2<NANT>(cols, r, q, a0, a1);
-            const double2 c = load_col2(qcol + r);
-            if (r + 1 >= R) a1 = NO_RULE_STATE_PART;
+            double2 c = load_col2(qcol + r);
+            if (r + 1 >= R) { a1 = NO_RULE_STATE_PART; c.y = 0.0; }      // the phantom rule of an odd tail: weight exactly 0, nothing of it is read
             q_pair(a0, a1, c, (unsigned)r, pk, best, sv, sw, tw0, tw1);
         }
         if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, sw);
@@ -570,10 +570,10 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         double s0 = 0.0, s1 = 0.0;
         if (NS > 0) sq_dist2<(NS > 0 ? NS : 1)>(cols, r, qs, s0, s1);
-        const double2 va = cols.pair(NS, r);
-        const double2 c = load_col2(qcol + r);
+        double2 va = cols.pair(NS, r);
+        double2 c = load_col2(qcol + r);
         const bool second = (r + 1 < R);
-        if (!second) s1 = NO_RULE_STATE_PART;
+        if (!second) { s1 = NO_RULE_STATE_PART; va.y = 0.0; c.y = 0.0; }
         note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
 #pragma unroll
         for (int a = 0; a < AMAX; a++)
@@ -682,7 +682,7 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                 a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
-            if (!second) a1 = NO_RULE_STATE_PART;
+            if (!second) { a1 = NO_RULE_STATE_PART; c.y = 0.0; }
             q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
         }
         if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);
@@ -698,8 +698,8 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                     s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
                 }
             }
-            const double2 va = v[NS];
-            if (!second) s1 = NO_RULE_STATE_PART;
+            double2 va = v[NS];
+            if (!second) { s1 = NO_RULE_STATE_PART; va.y = 0.0; c.y = 0.0; }
             note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
 #pragma unroll
             for (int a = 0; a < AMAX; a++)
@@ -787,7 +787,7 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
     for (int r = 2 * (int)threadIdx.x; r < R; r += 2 * BLOCK) {
         const bool second = (r + 1 < R);
         double2 v[NANT];
-        const double2 c = nc;
+        double2 c = nc;
 #pragma unroll
         for (int k = 0; k < NANT; k++) v[k] = cols.decode(k, nraw[k]);        // decode first, then refill (see sweep_gba_q)
         if (r + 2 * BLOCK < R) {
@@ -803,7 +803,7 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
                 d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                 a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
             }
-            if (!second) a1 = NO_RULE_STATE_PART;
+            if (!second) { a1 = NO_RULE_STATE_PART; c.y = 0.0; }
             double tw0, tw1;
             q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
         }
@@ -817,8 +817,8 @@ __device__ int sweep_gba_many(const COLS &cols, const double *__restrict__ qcol,
                 s0 = __fma_rn(d0, d0, s0); s1 = __fma_rn(d1, d1, s1);
             }
         }
-        const double2 va = v[NS];
-        if (!second) s1 = NO_RULE_STATE_PART;
+        double2 va = v[NS];
+        if (!second) { s1 = NO_RULE_STATE_PART; va.y = 0.0; c.y = 0.0; }
         note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
 #pragma unroll
         for (int g = 0; g < AMAX / G; g++) {
@@ -959,7 +959,7 @@ __device__ int sweep_gba_wide(const COLS &cols, const double *__restrict__ qcol,
                     d0 = q1[k] - v[k].x; d1 = q1[k] - v[k].y;
                     a0 = __fma_rn(d0, d0, a0); a1 = __fma_rn(d1, d1, a1);
                 }
-                if (!second) a1 = NO_RULE_STATE_PART;
+                if (!second) { a1 = NO_RULE_STATE_PART; c.y = 0.0; }
                 q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
             }
             if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw);

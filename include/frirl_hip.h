@@ -97,7 +97,7 @@ int frirl_hip_device_count(void);                 /* number of visible gfx950 de
 int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, int64_t *hbm_bytes);
 
 /* Experiment / test switches by name: "no_uidx" (1 = ignore the 16-bit index mirror), "rd_unroll", "rd_chunk", "rd_nt",
- * "rd_persist", "rd_order", "step_wave", "step_track", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices", "rollout_resident", "rollout_cap", "rollout_wps", "learn_slices", "learn_persistent", "no_many", "mirror_sync".  Their defaults
+ * "rd_persist", "rd_order", "step_wave", "step_track", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices", "rollout_resident", "rollout_cap", "rollout_wps", "learn_slices", "learn_persistent", "multi_loopback", "no_many", "mirror_sync".  Their defaults
  * (the shipped configuration) are read ONCE from the matching FRIRL_HIP_<NAME> environment variable, never per launch;
  * results do not depend on any of them (only the kernel variant / launch shape does). */
 int frirl_hip_set_option(const char *name, int value);
@@ -330,7 +330,7 @@ int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_ruleb
  * snapshot, :68-72) -- until it has converged, has made budget_steps steps in this call, or has run max_episodes - 1 episodes
  * (:51,59).  Nothing in a launch waits for the longest episode of the batch: the reference's many-agent modes diversify the start
  * states (frirl_agent.c:121-139), so agents are never in step.  Between calls the host compacts the agents that are still learning
- * into `live`; the fewer they are, the more lanes each gets (4 / 16 / 64 rule slices per agent).
+ * into `live`; the fewer they are, the more lanes each gets (2 ... 64 rule slices per agent: the largest power of two that keeps all of them resident).
  * State: envs->done[e] != 0 on entry means "between two episodes" (set it to 1 for a fresh agent; frirl_hip_convergence_init first);
  * on return done[e] = 1 iff the agent stopped at an episode boundary, ep_steps / ep_reward = the running or last episode,
  * conv->episodes / converged / prev_* as frirl_hip_convergence_update leaves them, status[e] = FRIRL_HIP_UPD_FULL iff an append was

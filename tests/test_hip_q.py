@@ -275,3 +275,33 @@ def test_shared_rule_base_evaluation_synthetic_shapes(nant, U, R, A):
         if len(srt) < 2 or (srt[-1] - srt[-2]) > 1e-9 * max(1.0, abs(srt[-1])):
             assert best[i] == bo
     assert hits >= Qn // 10
+
+
+@pytest.mark.parametrize("nant,U,R,A,compressed", [(3, 41, 111, 3, False), (5, 41, 367, 3, True), (5, 1001, 183, 21, True), (5, 41, 4097, 3, True), (4, 101, 301, 10, False)])
+def test_rows_beyond_nrules_are_never_read_into_a_result(nant, U, R, A, compressed):
+    """The slab beyond nrules[e] is the caller's memory (a C host that hipMallocs without memset): NaN there -- the phantom second
+    rule of an odd tail included -- must not reach any conclusion, weight or greedy action.  Odd rule counts everywhere."""
+    import torch
+    E = 9 if A <= 8 else 259
+    b = Batch(nant, U, R, E, A=A, seed=21 + R, ragged=True, maxR=R + 7)
+    b.nrules[b.nrules == 0] = 1
+    b.nrules[b.nrules % 2 == 0] -= 1
+    b.nrules[0] = R
+    ave, _ = b.action_ve()
+    x = b.queries(seed=R, hit_fraction=0.4)
+    clean = b.to_device(compressed=compressed)
+    for e in range(E):
+        b.rb[e, :, int(b.nrules[e]):] = np.nan
+    dirty = b.to_device(compressed=compressed)
+    states = np.ascontiguousarray(x[:, : nant - 1])
+    for prob in (clean, dirty):
+        prob.out = (prob.vag_concl(dev(x)), prob.get_best_action(dev(states), dev(ave)), prob.vag_concl_weight(dev(x)))
+    torch.cuda.synchronize()
+    (c0, h0), (a0, b0), (w0, _) = clean.out
+    (c1, h1), (a1, b1), (w1, _) = dirty.out
+    assert torch.isfinite(c1).all() and torch.isfinite(a1).all()
+    assert (c0 == c1).all() and (h0 == h1).all() and (a0 == a1).all() and (b0 == b1).all()
+    for e in range(E):
+        n = int(b.nrules[e])
+        if int(h1[e]) < 0 or int(h1[e]) == 0xFFFFFFFF or int(h1[e]) >= n:
+            assert (w0[e, :n] == w1[e, :n]).all() and torch.isfinite(w1[e, :n]).all()

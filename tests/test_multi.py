@@ -85,3 +85,57 @@ def test_c_level_rule_base_exchange_across_devices_on_one_device(env, agents, ma
     one = np.loadtxt(tmp_path / f"{env}.merged.frirlrb.txt", dtype=np.float64, ndmin=2)
     multi = np.loadtxt(tmp_path / f"{env}.multi.merged.frirlrb.txt", dtype=np.float64, ndmin=2)
     assert one.shape == multi.shape and (one.view(np.uint64) == multi.view(np.uint64)).all()
+
+
+def _demo(args, cwd, loopback=False):
+    env = dict(os.environ)
+    if loopback:
+        env["FRIRL_HIP_MULTI_LOOPBACK"] = "1"        # logical shards on the one device, device-to-device copies instead of RCCL
+    demo = os.path.join(frirl_amd.PKG_DIR, "lib", "frirl_demo")
+    r = subprocess.run([demo] + args, cwd=cwd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3])
+def test_c_level_runner_with_logical_shards(shards, tmp_path):
+    """frirl_hip_multi_train with G > 1: one host thread per shard, the report gathered from every shard and combined in shard order,
+    every shard leaving the loop in the same episode -- executed with 2 and 3 LOGICAL shards on the one device (loop-back
+    transport); same job report and same master rule base as one shard."""
+    frirl_amd.build()
+    one = _demo(["--env", "mountaincar", "--agents", "7", "--gpus", "1"], tmp_path)
+    a = np.loadtxt(tmp_path / "mountaincar.multi.frirlrb.txt", dtype=np.float64, ndmin=2)
+    many = _demo(["--env", "mountaincar", "--agents", "7", "--gpus", str(shards)], tmp_path, loopback=True)
+    b = np.loadtxt(tmp_path / "mountaincar.multi.frirlrb.txt", dtype=np.float64, ndmin=2)
+    assert f"gpus {shards} (RCCL -1)" in many and f"device {shards - 1} runs agents" in many, many
+    tail = lambda out: [ln.split("agents", 1)[1] for ln in out.splitlines() if ln.startswith("multi mountaincar: gpus")][-1]
+    assert tail(one) == tail(many), (one, many)
+    assert a.shape == b.shape and (a.view(np.uint64) == b.view(np.uint64)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,agents,shards,max_episodes", [("mountaincar", 7, 3, 22), ("acrobot", 5, 2, 12), ("mountaincar", 6, 6, 13)])
+def test_c_level_rule_base_exchange_with_logical_shards(env, agents, shards, max_episodes, tmp_path):
+    """frirl_hip_multi_train_merged with G > 1 -- the g > 0 / p >= 1 branches: the master's list broadcast to the other shards, their
+    rule lists packed (strided consequent copy), sent, received and merged into the master in GLOBAL agent order, "master complete"
+    riding in the report -- through the loop-back transport with 2, 3 and 6 logical shards (6 = one agent per shard; 7 agents over 3
+    shards = ragged shard sizes): episodes, merge rounds, job report and the master's rule base bit-identical to
+    frirl_hip_batch_train_merged on the same agents (itself checked against the oracle's loop in test_hip_merge.py)."""
+    frirl_amd.build()
+    base = ["--env", env, "--agents", str(agents), "--merge", "--max-episodes", str(max_episodes)]
+    a = _demo(base, tmp_path)
+    b = _demo(base + ["--gpus", str(shards)], tmp_path, loopback=True)
+    assert f"gpus {shards} (RCCL -1)" in b, b
+
+    def fields(out):
+        line = [ln for ln in out.splitlines() if ln.startswith("merged ")][-1]
+        tok = line.split()
+        return {k: tok[tok.index(k) + 1] for k in ("agents", "episodes", "merge-rounds", "converged", "env-steps", "mean-rules", "mean-reward")}
+
+    fa, fb = fields(a), fields(b)
+    assert fa == fb, (fa, fb)
+    assert int(fa["merge-rounds"]) >= 1
+    one = np.loadtxt(tmp_path / f"{env}.merged.frirlrb.txt", dtype=np.float64, ndmin=2)
+    multi = np.loadtxt(tmp_path / f"{env}.multi.merged.frirlrb.txt", dtype=np.float64, ndmin=2)
+    assert one.shape == multi.shape and (one.view(np.uint64) == multi.view(np.uint64)).all()
