@@ -14,6 +14,7 @@ reference's exported C API and each example's own main().  What is committed is 
   tests/golden/vec_<env>.jsonl        function-level vectors (tables, index snap, rule distance,
                                       vag_concl, weights, best action, SARSA updates, env steps)
                                       on the rule base reached after a few episodes
+  tests/golden/omprun_<env>_<N>.jsonl the genuine frirl_omp_run (5 agents, max_episodes N): master's final rule base + episode / "pended" counts
   tests/golden/merge_<env>.jsonl      multi-agent rule-base merge (frirl_agent.c merge_rb / gen_def_states / omp_init, compiled with
                                       BUILD_OPENMP by oracle/_ref/ref_merge_harness): master and agent rule bases before and
                                       after merging in both directions
@@ -21,7 +22,7 @@ reference's exported C API and each example's own main().  What is committed is 
                                       in the tests by oracle orc_synth_*; nant <= 8 only, the
                                       reference's cap is FIVE_MAX_NUM_OF_UNIVERSES = 8)
 """
-import os, shutil, subprocess, sys
+import json, os, shutil, subprocess, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -31,6 +32,7 @@ HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 ENVS = ["mountaincar", "cartpole", "acrobot"]
 VEC_EPISODES = {"mountaincar": 6, "cartpole": 9, "acrobot": 5}
 MERGE_EPISODES = {"mountaincar": (8, 3), "cartpole": (10, 4), "acrobot": (6, 3)}
+OMPRUN = [("mountaincar", 1000), ("cartpole", 15), ("cartpole", 40), ("acrobot", 15), ("acrobot", 40)]      # (env, max_episodes), 5 agents
 SYNTH = [  # nant, U, R, A, seed, nq
     (3, 41, 33, 3, 11, 64),
     (5, 41, 367, 3, 12, 64),
@@ -72,6 +74,16 @@ def main():
         m_eps, a_eps = MERGE_EPISODES[e]
         with open(os.path.join(tmp, f"{e}.mstdout"), "w") as so:
             run(os.path.join(HERE, "_ref", "ref_merge_harness"), e, os.path.join(GOLD, f"merge_{e}.jsonl"), str(m_eps), str(a_eps), stdout=so)
+    # the GENUINE many-agent loop with rule-base exchange (frirl_omp_run, unmodified) on 5 agents: the master's final rule base,
+    # and from its own printouts the episodes run by all agents and the exchanges skipped because an agent had "pended"
+    for e, max_eps in OMPRUN:
+        out = os.path.join(GOLD, f"omprun_{e}_{max_eps}.jsonl")
+        so_path = os.path.join(tmp, f"{e}.ostdout")
+        with open(so_path, "w") as so:
+            run(os.path.join(HERE, "_ref", "ref_merge_harness"), e, out, "omprun", "5", str(max_eps), stdout=so, stderr=subprocess.DEVNULL)
+        txt = open(so_path).read()
+        with open(out, "a") as f:
+            f.write(json.dumps({"k": "stdout_counts", "episode_lines": txt.count("Episode:"), "pended_lines": txt.count("pended")}) + "\n")
     if "--merge-only" in sys.argv:
         return
     for (nant, U, R, A, seed, nq) in SYNTH:

@@ -388,3 +388,23 @@ def test_portable_trig_env_steps_that_differ_from_glibc(golden_dir):
                 worst = max(worst, float(np.abs(ns - want).max()))
             assert rew == fh(r["r"]) and f == r["f"] and (bits(q) == bits(fha(r["q"]))).all()
     assert total == 900 and differing <= 60 and worst <= 1e-13, (differing, total, worst)
+
+
+# ---- the many-agent loop WITH rule-base exchange, as a whole: frirl_omp_run of the genuine reference (5 agents) -----------------
+OMPRUN = [("mountaincar", 1000), ("cartpole", 15), ("cartpole", 40), ("acrobot", 15), ("acrobot", 40)]
+
+
+@pytest.mark.parametrize("env,max_episodes", OMPRUN)
+def test_omp_run_loop_matches_reference(env, max_episodes, golden_dir):
+    """tests/omp_model.py (chunks of 9 episodes through frirl_sequential_run's loop, `epended` per chunk from the cheap test alone,
+    finished agents running again, previous-episode values surviving the merge; frirl_agent.c:294-385) against the GENUINE
+    frirl_omp_run compiled with BUILD_OPENMP (oracle/ref_merge_harness `omprun`): the master's final rule base bit for bit, the
+    number of episodes all agents ran and the number of exchanges skipped because an agent had "pended"."""
+    from tests import omp_model
+    recs = {r["k"]: r for r in load_jsonl(os.path.join(golden_dir, f"omprun_{env}_{max_episodes}.jsonl"))}
+    assert (recs["hdr"]["world"], recs["hdr"]["max_episodes"]) == (5, max_episodes)
+    ag, rounds, pended = omp_model.run_omp(env, 5, max_episodes, trig_mode=0)
+    same_rule_base(ag[0].fr.five, recs["master_final"], ag[0].fr.nant)
+    assert sum(a.episodes_run for a in ag) == recs["stdout_counts"]["episode_lines"]
+    assert pended == recs["stdout_counts"]["pended_lines"]
+    assert rounds >= 1
