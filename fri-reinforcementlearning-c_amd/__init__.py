@@ -75,7 +75,7 @@ class ReduceResult(C.Structure):
 class ConvergenceDesc(C.Structure):
     """struct frirl_hip_convergence (include/frirl_hip.h)."""
     _fields_ = [("prev_nrules", C.c_void_p), ("prev_steps", C.c_void_p), ("prev_reward", C.c_void_p), ("prev_rconc", C.c_void_p),
-                ("converged", C.c_void_p), ("episodes", C.c_void_p)]
+                ("converged", C.c_void_p), ("episodes", C.c_void_p), ("epended", C.c_void_p)]
 
 
 _lib = None
@@ -522,8 +522,9 @@ class Convergence:
         self.converged = torch.zeros((E,), dtype=torch.int32, device=device)
         self.episodes = torch.zeros((E,), dtype=torch.int32, device=device)
         self.full = torch.zeros((E,), dtype=torch.bool, device=device)     # agents whose rule base refused an append (capacity)
+        self.epended = torch.zeros((E,), dtype=torch.int32, device=device)  # the cheap "same as the previous episode" test held (frirl_desc.epended)
         self.desc = ConvergenceDesc(self.prev_nrules.data_ptr(), self.prev_steps.data_ptr(), self.prev_reward.data_ptr(),
-                                    self.prev_rconc.data_ptr(), self.converged.data_ptr(), self.episodes.data_ptr())
+                                    self.prev_rconc.data_ptr(), self.converged.data_ptr(), self.episodes.data_ptr(), self.epended.data_ptr())
         check(lib().frirl_hip_convergence_init(C.byref(problem.bases), problem.nant, C.byref(self.desc), _stream()), "frirl_hip_convergence_init")
 
     @property

@@ -25,7 +25,7 @@ struct frirl_hip_batch {
     int32_t *d_spread_R;
     void *d_lanes_ws;            // transposed rule bases of the lane-group kernel (allocated on first use)
     size_t lanes_ws_bytes;
-    int32_t *d_nrules, *d_fus, *d_done, *d_ep_steps, *d_status, *d_episode, *d_prev_nrules, *d_prev_steps, *d_converged, *d_episodes;
+    int32_t *d_nrules, *d_fus, *d_done, *d_ep_steps, *d_status, *d_episode, *d_prev_nrules, *d_prev_steps, *d_converged, *d_episodes, *d_epended;
     frirl_hip_tables t;
     frirl_hip_rulebases rb;
     frirl_hip_agent agent;
@@ -55,6 +55,15 @@ __global__ void mask_converged_kernel(int32_t *__restrict__ done, const int32_t 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E && converged[e]) done[e] = 1;
 }
+// end of an exchange round: every agent but the master runs again in the next round whether or not its rule base was complete
+// (frirl_sequential_run does not look at is_running on entry, frirl_agent.c:321-328), and `epended` starts every chunk at 0 (:37)
+__global__ void next_round_kernel(int32_t *__restrict__ converged, int32_t *__restrict__ epended, int E, int first)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    epended[e] = 0;
+    if (e >= first) converged[e] = 0;
+}
 // number of agents whose episode is still running -> *out
 __global__ void count_running_kernel(const int32_t *__restrict__ done, int E, int32_t *__restrict__ out)
 {
@@ -77,7 +86,7 @@ extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
     if (b->s) (void)hipStreamSynchronize(b->s);
     void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
                     b->d_prev_rconc, b->d_tmp, b->d_nrules, b->d_fus, b->d_done, b->d_ep_steps, b->d_status, b->d_episode, b->d_prev_nrules,
-                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_uidx, b->d_lanes_ws, b->d_weights, b->d_active, b->d_full, b->d_spread_ant, b->d_spread_R};
+                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_epended, b->d_uidx, b->d_lanes_ws, b->d_weights, b->d_active, b->d_full, b->d_spread_ant, b->d_spread_R};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->s) (void)hipStreamDestroy(b->s);
     delete b;
@@ -100,7 +109,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
     ok = ok && dalloc(&b->d_states, E * ns) && dalloc(&b->d_q_ant, E * n) && dalloc(&b->d_ep_reward, E) && dalloc(&b->d_prev_reward, E);
     ok = ok && dalloc(&b->d_prev_rconc, E * M) && dalloc(&b->d_tmp, E * (n + 1)) && dalloc(&b->d_nrules, E) && dalloc(&b->d_fus, E) && dalloc(&b->d_done, E);
     ok = ok && dalloc(&b->d_ep_steps, E) && dalloc(&b->d_status, E) && dalloc(&b->d_episode, E) && dalloc(&b->d_prev_nrules, E) && dalloc(&b->d_prev_steps, E);
-    ok = ok && dalloc(&b->d_converged, E) && dalloc(&b->d_episodes, E + 1) && dalloc(&b->d_spread_ant, E * n) && dalloc(&b->d_spread_R, E);
+    ok = ok && dalloc(&b->d_converged, E) && dalloc(&b->d_episodes, E + 1) && dalloc(&b->d_epended, E) && dalloc(&b->d_spread_ant, E * n) && dalloc(&b->d_spread_R, E);
     if (ok && d->U <= 65536) ok = dalloc(&b->d_uidx, E * n * M);
     if (ok && d->start_states) ok = dalloc(&b->d_start, E * ns) && hipMemcpy(b->d_start, d->start_states, sizeof(double) * E * ns, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(b->d_u, d->u, sizeof(double) * n * d->U, hipMemcpyHostToDevice) == hipSuccess;
@@ -118,7 +127,7 @@ extern "C" frirl_hip_batch *frirl_hip_batch_create(const frirl_hip_batch_desc *d
     b->envs.ep_reward = b->d_ep_reward; b->envs.rant = b->d_rant; b->envs.status = b->d_status; b->envs.start_states = b->d_start; b->envs.episode = b->d_episode;
     b->envs.spread_ant = b->d_spread_ant; b->envs.spread_R = b->d_spread_R;
     b->conv.prev_nrules = b->d_prev_nrules; b->conv.prev_steps = b->d_prev_steps; b->conv.prev_reward = b->d_prev_reward; b->conv.prev_rconc = b->d_prev_rconc;
-    b->conv.converged = b->d_converged; b->conv.episodes = b->d_episodes;
+    b->conv.converged = b->d_converged; b->conv.episodes = b->d_episodes; b->conv.epended = b->d_epended;
     b->total_env_steps = 0;
     // initial rules through FIVE_add_rule, as FIVEInit does (every agent gets the same R0 rules)
     std::vector<double> stage(E * (n + 1));
@@ -272,24 +281,25 @@ extern "C" int frirl_hip_batch_reduce(frirl_hip_batch *b, int32_t e, int strateg
 // ---- multi-agent rule-base merge: one round of the reference's many-agent loop (frirl_agent.c:426-462) -------------------
 // (1) every agent id >= 1 takes over the master's (agent 0's) rules -- all receivers in ONE launch; (2) the master takes over the
 // rules of agent 1, 2, ... one after the other (sequential by definition: each merge changes the master).  Agents whose rule base
-// is complete ("epended": converged[]) do not send, as in the reference (:432,:444).
+// passed the cheap completeness test in this chunk (`epended`) do not send, as in the reference (frirl_agent.c:338,352).
 // ---- the pieces of a merge round (batch_internal.h; also strung together across devices by multi.hip) --------------------------
 namespace frirl_host {
 
 BatchView batch_view(frirl_hip_batch *b)
 {
-    return BatchView{b->nant, b->maxR, b->E, b->device, b->s, b->d_rant, b->d_rb, b->d_nrules, b->d_converged};
+    return BatchView{b->nant, b->maxR, b->E, b->device, b->s, b->d_rant, b->d_rb, b->d_nrules, b->d_converged, b->d_epended};
 }
 
-int batch_merge_prepare(frirl_hip_batch *b, std::vector<int32_t> &conv)
+int batch_merge_prepare(frirl_hip_batch *b, std::vector<int32_t> &pended)
 {
+    std::vector<int32_t> &conv = pended;
     DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t M = b->maxR, E = b->E;
     if (!b->d_weights) {
         if (!dalloc(&b->d_weights, E * M) || !dalloc(&b->d_active, E) || !dalloc(&b->d_full, E)) { set_error("frirl_hip_batch_merge_round: allocation failed"); return FRIRL_HIP_ELAUNCH; }
     }
     conv.resize(E);
-    BCHK(hipMemcpyAsync(conv.data(), b->d_converged, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "converged download");
+    BCHK(hipMemcpyAsync(conv.data(), b->d_epended, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "epended download");
     BCHK(hipStreamSynchronize(b->s), "merge sync");
     // the receivers' FIVERB.weights as the learning episodes left them (the reference's merge starts from that array)
     return frirl_hip_weights_from_spread(&b->t, &b->rb, b->agent.p, &b->envs, b->d_weights, b->s);
@@ -329,7 +339,7 @@ frirl_hip_sender batch_sender(frirl_hip_batch *b, int id)
     return snd;
 }
 
-int batch_merge_finish(frirl_hip_batch *b, int32_t *full_agents)
+int batch_merge_finish(frirl_hip_batch *b, int32_t *full_agents, bool first_is_master)
 {
     DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
     const size_t E = b->E;
@@ -337,7 +347,8 @@ int batch_merge_finish(frirl_hip_batch *b, int32_t *full_agents)
     BCHK(hipMemcpyAsync(b->h_i.data(), b->d_nrules, sizeof(int32_t) * E, hipMemcpyDeviceToHost, b->s), "nrules download");
     BCHK(hipStreamSynchronize(b->s), "merge sync");
     if (full_agents) for (size_t e = 0; e < E; e++) *full_agents += b->h_i[e] >= b->maxR;
-    // the merged rule bases are new starting points: the "same as the previous episode" test restarts from them (prev_* refreshed)
+    hipLaunchKernelGGL(frirl::next_round_kernel, dim3((b->E + 255) / 256), dim3(256), 0, b->s, b->d_converged, b->d_epended, b->E, first_is_master ? 1 : 0);
+    // rule count and consequents of the next convergence test are retaken from the merged rule bases (frirl_sequential_run.c:66-72)
     const int rc = frirl_hip_convergence_refresh(&b->rb, b->nant, &b->conv, b->s);
     if (rc) return rc;
     BCHK(hipStreamSynchronize(b->s), "merge sync");
@@ -363,31 +374,35 @@ extern "C" int frirl_hip_batch_merge_round(frirl_hip_batch *b, int32_t *full_age
         const frirl_hip_sender snd = batch_sender(b, id);
         if ((rc = batch_merge_into_first(b, &snd))) return rc;
     }
-    return batch_merge_finish(b, full_agents);
+    return batch_merge_finish(b, full_agents, true);
 }
 
-// frirl_omp_run's loop (frirl_agent.c:424-462) for the agents of this batch: rounds of `chunk - 1` episodes per agent
-// (FRIRL_AGENT_EPCHUNK = 10 in the reference's config.h.in:68), then one merge round, until the master's rule base is complete or
-// max_episodes - 1 episodes have run.
+// frirl_omp_run's loop (frirl_agent.c:319-360) for the agents of this batch: every round each agent runs a chunk of at most
+// `chunk - 1` episodes (FRIRL_AGENT_EPCHUNK = 10 in the reference's config.h.in:68; an agent whose rule base is found complete stops
+// for the rest of ITS chunk and runs again in the next round), then one exchange round gated by that chunk's `epended` flags -- until
+// the master's rule base is complete or the master has started max_episodes episodes, which frirl_sequential_run only looks at when a
+// chunk is over (:57-63): the master always finishes its chunk.  *episodes_run = the master's episodes.
 extern "C" int frirl_hip_batch_train_merged(frirl_hip_batch *b, int32_t max_episodes, int32_t chunk, int32_t *episodes_run, int32_t *rounds)
 {
     if (!b || chunk < 2) { set_error("frirl_hip_batch_train_merged: bad arguments"); return FRIRL_HIP_EINVAL; }
     DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
-    int ep = 1, nrounds = 0;
+    int episode_num = 1, episodes = 0, nrounds = 0;         // frirl_desc.episode_num of the master starts at 1 (frirl_init.c)
     for (;;) {
         int32_t master_done = 0;
-        for (int c = 1; c < chunk && ep < max_episodes; c++, ep++) {
+        for (int c = 1; c < chunk; c++) {
             const int rc = frirl_hip_batch_episode(b);
             if (rc) return rc;
+            episodes++;
             BCHK(hipMemcpy(&master_done, b->d_converged, sizeof(int32_t), hipMemcpyDeviceToHost), "converged download");
-            if (master_done) { ep++; break; }
+            if (master_done) break;
+            episode_num++;
         }
-        if (master_done || ep >= max_episodes) break;
+        if (master_done || !(episode_num < max_episodes)) break;
         const int rc = frirl_hip_batch_merge_round(b, nullptr);
         if (rc) return rc;
         nrounds++;
     }
-    if (episodes_run) *episodes_run = ep - 1;
+    if (episodes_run) *episodes_run = episodes;
     if (rounds) *rounds = nrounds;
     return FRIRL_HIP_OK;
 }

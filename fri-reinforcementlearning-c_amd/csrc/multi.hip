@@ -532,6 +532,7 @@ static int merge_round_shard(frirl_hip_multi *m, int g, int32_t *full_agents)
         MCHK(hipMemcpyAsync(sh.d_stage, v.d_rant, sizeof(double) * n * M, hipMemcpyDeviceToDevice, v.s), "master rows");
         MCHK(hipMemcpyAsync(sh.d_stage + n * M, v.d_rb + n * M, sizeof(double) * M, hipMemcpyDeviceToDevice, v.s), "master consequents");
         MCHK(hipMemcpyAsync(sh.d_stage_i, v.d_nrules, sizeof(int32_t), hipMemcpyDeviceToDevice, v.s), "master rule count");
+        if (conv[0]) MCHK(hipMemsetAsync(sh.d_stage_i, 0, sizeof(int32_t), v.s), "master pended");      // "#0 pended, skipping sync to master": nobody takes its rules over (:338-350)
     }
     TCHK(tr.broadcast(g, sh.d_stage, sizeof(double) * (n + 1) * M, 0, v.s));
     TCHK(tr.broadcast(g, sh.d_stage_i, sizeof(int32_t), 0, v.s));
@@ -544,7 +545,7 @@ static int merge_round_shard(frirl_hip_multi *m, int g, int32_t *full_agents)
         const size_t c = (size_t)sh.count;
         MCHK(hipMemcpy2DAsync(sh.d_pack_rconc, sizeof(double) * M, v.d_rb + n * M, sizeof(double) * (n + 1) * M, sizeof(double) * M, c, hipMemcpyDeviceToDevice, v.s), "pack consequents");
         MCHK(hipMemcpyAsync(sh.d_pack_i, v.d_nrules, sizeof(int32_t) * c, hipMemcpyDeviceToDevice, v.s), "pack rule counts");
-        MCHK(hipMemcpyAsync(sh.d_pack_i + c, v.d_converged, sizeof(int32_t) * c, hipMemcpyDeviceToDevice, v.s), "pack flags");
+        MCHK(hipMemcpyAsync(sh.d_pack_i + c, v.d_epended, sizeof(int32_t) * c, hipMemcpyDeviceToDevice, v.s), "pack flags");
         TCHK(tr.begin(g));
         TCHK(tr.send(g, v.d_rant, sizeof(double) * c * n * M, 0, v.s));
         TCHK(tr.send(g, sh.d_pack_rconc, sizeof(double) * c * M, 0, v.s));
@@ -564,7 +565,7 @@ static int merge_round_shard(frirl_hip_multi *m, int g, int32_t *full_agents)
         }
         TCHK(wait_stream(m, g, v.s, "exchange"));
         for (int id = 1; id < v.E; id++) {                       // this shard's own agents come first in the global order
-            if (conv[id]) continue;                              // a complete rule base does not send (:432,:444)
+            if (conv[id]) continue;                              // an agent that has "pended" in this chunk does not send (:352-358)
             const frirl_hip_sender own = batch_sender(sh.batch, id);
             if ((rc = batch_merge_into_first(sh.batch, &own))) return rc;
         }
@@ -581,7 +582,7 @@ static int merge_round_shard(frirl_hip_multi *m, int g, int32_t *full_agents)
         }
     }
     // (3)
-    return batch_merge_finish(sh.batch, full_agents);
+    return batch_merge_finish(sh.batch, full_agents, g == 0);
 }
 
 extern "C" int frirl_hip_multi_train_merged(frirl_hip_multi *m, int32_t max_episodes, int32_t chunk, int32_t *episodes_run, int32_t *rounds)
@@ -591,22 +592,25 @@ extern "C" int frirl_hip_multi_train_merged(frirl_hip_multi *m, int32_t max_epis
     std::vector<int> eps(G, 0), nrounds(G, 0);
     const int rc = run_shards(m, "frirl_hip_multi_train_merged", [&](int g) {
         Shard &sh = m->shards[g];
-        int ep = 1, nr = 0;
+        int episode_num = 1, episodes = 0, nr = 0;          // the master's frirl_desc.episode_num; every shard counts the same way
         bool stop = false;
-        while (!stop) {                                         // frirl_omp_run's loop (frirl_agent.c:424-462): every shard takes the same path
+        while (!stop) {                                         // frirl_omp_run's loop (frirl_agent.c:319-360): every shard takes the same path
             bool master_done = false;
-            for (int c = 1; c < chunk && ep < max_episodes; c++, ep++) {
+            for (int c = 1; c < chunk; c++) {                   // a whole chunk: max_episodes is looked at when it is over (frirl_sequential_run.c:57-63)
                 const int erc = frirl_hip_batch_episode(sh.batch);
+                episodes++;
                 const int rrc = shard_report(m, g, erc);
-                if (rrc) { if (!sh.rc) shard_failed(m, g, rrc, "report", ep); stop = true; break; }
+                if (rrc) { if (!sh.rc) shard_failed(m, g, rrc, "report", episodes); stop = true; break; }
                 master_done = sh.h_stat[7] > 0.0;
-                if (master_done) { ep++; break; }
+                if (master_done) break;
+                episode_num++;
             }
-            if (stop || master_done || ep >= max_episodes) break;
+            if (stop || master_done || !(episode_num < max_episodes)) break;
             const int mrc = merge_round_shard(m, g, nullptr);
-            if (mrc) { shard_failed(m, g, mrc, "merge round", ep); break; }
+            if (mrc) { shard_failed(m, g, mrc, "merge round", episodes); break; }
             nr++;
         }
+        int ep = episodes + 1;
         eps[g] = ep - 1;
         nrounds[g] = nr;
     });

@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256) void convergence_kernel(const double *__restri
         __syncthreads();
         if (threadIdx.x == 0) {
             c.episodes[e] = c.episodes[e] + 1;
+            if (same && c.epended) c.epended[e] = 1;                                                      // :88-90, before the tolerance check
             if (same && !moved_s) c.converged[e] = 1;
         }
     }
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void convergence_kernel(const double *__restri
     if (threadIdx.x == 0) {
         c.prev_nrules[e] = R;                                                                             // :68-70
         if (init == 1) { c.prev_steps[e] = -1; c.prev_reward[e] = -1.0; c.converged[e] = 0; c.episodes[e] = 0; }   // frirl_init.c:149-150
-        else if (init == 2) { c.prev_steps[e] = -1; c.prev_reward[e] = -1.0; }                                   // refresh after a merge
+        else if (init == 2) { }                                     // refresh after a merge: steps / reward of the last episode stay (:66-68)
         else { c.prev_steps[e] = ev.ep_steps[e]; c.prev_reward[e] = ev.ep_reward[e]; }
     }
 }

@@ -251,6 +251,11 @@ typedef struct frirl_hip_convergence {
     double *prev_rconc;      /* [dev] [E][maxR] consequents after the previous episode                    */
     int32_t *converged;      /* [dev] [E] 1 once "RB considered complete" (sticky)                        */
     int32_t *episodes;       /* [dev] [E] episodes run until convergence (counts while not converged)     */
+    int32_t *epended;        /* [dev] [E] or NULL: set to 1 by frirl_hip_convergence_update when the CHEAP test alone holds (same #rules,
+                                #steps and good reward as the previous episode, frirl_sequential_run.c:83-90 -- `frirl_desc.epended`, which
+                                stays set even when the tolerance check then finds a consequent that moved); never cleared by the
+                                library's kernels: the many-agent loop clears it at the start of every chunk and gates that round's
+                                rule-base exchange with it (frirl_agent.c:338,352) */
 } frirl_hip_convergence;
 
 /* ---- one SHARED, read-only rule base, many observations (evaluation of a trained rule base, e.g.
@@ -365,7 +370,9 @@ int frirl_hip_convergence_init(const frirl_hip_rulebases *b, int nant, const fri
 int frirl_hip_convergence_update(const frirl_hip_rulebases *b, int nant, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
                                  const frirl_hip_convergence *c, void *stream);
 /* after the rule bases were changed outside an episode (frirl_hip_merge_rb): retake the snapshot (rule count, consequents) the next
- * convergence test compares with; converged agents keep theirs */
+ * convergence test compares with -- what the reference does at the top of every episode (frirl_sequential_run.c:66-72).  The previous
+ * episode's steps and reward are NOT touched: they live in frirl_desc.reward and survive a merge, so an agent can be found complete
+ * on its first episode after one.  Converged agents keep their snapshot. */
 int frirl_hip_convergence_refresh(const frirl_hip_rulebases *b, int nant, const frirl_hip_convergence *c, void *stream);
 
 /* ---- FIVEVagConcl_FRIRL_BestAct (reference src/five/FIVEVagConcl_FRIRL_BestAct.c:56-299) -------

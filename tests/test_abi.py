@@ -46,7 +46,7 @@ def test_agent_and_envs_struct_layouts():
     assert A.skip_rules.offset == 40 and A.grid_len.offset == 64 and A.grid_div.offset == 128 and A.values_def.offset == 256
     assert A.grid_values.offset == 384 and A.action_ve.offset == 392 and A.epsilon.offset == 400 and A.seed.offset == 424 and A.evaluate.offset == 432 and A.env_id_base.offset == 440 and C.sizeof(A) == 448
     assert C.sizeof(E) == 96 and E.status.offset == 56 and E.episode.offset == 72 and E.spread_ant.offset == 80 and E.spread_R.offset == 88
-    assert C.sizeof(frirl_amd.ConvergenceDesc) == 48
+    assert C.sizeof(frirl_amd.ConvergenceDesc) == 56 and frirl_amd.ConvergenceDesc.epended.offset == 48
 
 
 def test_argument_validation_and_no_cpu_fallback(lib):

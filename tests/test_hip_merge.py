@@ -148,57 +148,25 @@ def test_merge_rb_capacity_and_sender_from_device_rows():
     assert int(small.nrules[0]) == 34 and int(full_s[0]) == 1
 
 
-@pytest.mark.parametrize("env,agents", [("mountaincar", 4), ("acrobot", 5)])
-def test_c_level_merged_training_follows_the_oracle(env, agents, tmp_path):
-    """`frirl_demo --agents N --merge`: the reference's many-agent loop with rule-base exchange (frirl_omp_run,
-    frirl_agent.c:424-462) through the C-level batch object: start states from gen_def_states, 9 episodes per agent, one merge
-    round (every agent <- master in one launch, then master <- agent 1, 2, ...), then the remaining episodes.  The same loop
-    written with the oracle's pieces (each pinned against the genuine reference) must give the master's rule base: antecedents and
-    order exact, consequents within 1e-6."""
+@pytest.mark.parametrize("env,agents,max_episodes", [("mountaincar", 5, 1000), ("mountaincar", 4, 15), ("acrobot", 5, 15), ("acrobot", 5, 40), ("cartpole", 5, 15)])
+def test_c_level_merged_training_follows_the_reference_loop(env, agents, max_episodes, tmp_path):
+    """`frirl_demo --agents N --merge`: the reference's many-agent loop with rule-base exchange (frirl_omp_run, frirl_agent.c:294-385)
+    through the C-level batch object, against tests/omp_model.py -- the same loop written with the oracle's pieces and pinned as a
+    WHOLE against the genuine frirl_omp_run (tests/test_oracle_golden.py::test_omp_run_loop_matches_reference): chunks of 9 episodes,
+    `epended` per chunk from the cheap test alone, finished agents running again in the next round, the previous episode's steps and
+    reward surviving the merge, max_episodes looked at only when a chunk is over.  Master's episodes and rounds equal; its rule base:
+    antecedents and order exact, consequents within 1e-6 (portable trig on both sides)."""
     import subprocess
+    from tests import omp_model
     demo = os.path.join(frirl_amd.PKG_DIR, "lib", "frirl_demo")
-    r = subprocess.run([demo, "--env", env, "--agents", str(agents), "--merge", "--max-episodes", "12"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([demo, "--env", env, "--agents", str(agents), "--merge", "--max-episodes", str(max_episodes)], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "merge-rounds 1" in r.stdout and "episodes 11" in r.stdout, r.stdout
+    ag, rounds, pended = omp_model.run_omp(env, agents, max_episodes, trig_mode=1)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("merged ")][-1].split()
+    got = {k: int(line[line.index(k) + 1]) for k in ("episodes", "merge-rounds")}
+    assert got == {"episodes": ag[0].episodes_run, "merge-rounds": rounds}, (got, ag[0].episodes_run, rounds, r.stdout[-600:])
     mine = np.loadtxt(tmp_path / f"{env}.merged.frirlrb.txt", dtype=np.float64, ndmin=2)
-    ag = [ob.Frirl(env, trig_mode=1) for _ in range(agents)]
-    ns = ag[0].nstates
-    for i in range(1, agents):
-        ag[i].set_start_state(ag[0].five.gen_def_states(i, agents, ns))
-    hp = ag[0].hparams
-    # per-agent construct-loop bookkeeping (frirl_sequential_run.c:68-72,83-148): an agent whose rule base is complete ("epended")
-    # sits later episodes out and does not send its rules (frirl_agent.c:432,444)
-    prev = [dict(R=a.five.R, steps=-1, reward=-1.0, q=np.array(a.five.rconc[: a.five.maxR]).copy()) for a in ag]
-    done = [False] * agents
-
-    def episode_all():
-        for i, a in enumerate(ag):
-            if done[i]:
-                continue
-            a.episode()
-            f, pv = a.five, prev[i]
-            same = pv["R"] == f.R and pv["steps"] == a.ep_steps and a.ep_reward > hp["reward_good_above"] and pv["reward"] == a.ep_reward
-            if same and not (np.abs(np.array(f.rconc[: f.R]) - pv["q"][: f.R]) >= hp["qdiff_final_tolerance"]).any():
-                done[i] = True
-            prev[i] = dict(R=f.R, steps=a.ep_steps, reward=a.ep_reward, q=np.array(f.rconc[: f.maxR]).copy())
-
-    for _ in range(9):
-        episode_all()
-    assert not done[0]
-    m = ag[0].five
-    mr, mc = np.array(m.rant[: m.R]), np.array(m.rconc[: m.R])
-    for i in range(1, agents):
-        ag[i].five.merge_rb(ag[i].agent(), mr, mc)
-    for i in range(1, agents):
-        if done[i]:
-            continue
-        f = ag[i].five
-        m.merge_rb(ag[0].agent(), np.array(f.rant[: f.R]), np.array(f.rconc[: f.R]))
-    for i, a in enumerate(ag):        # the merged rule bases are the new reference points of the convergence test
-        if not done[i]:
-            prev[i] = dict(R=a.five.R, steps=-1, reward=-1.0, q=np.array(a.five.rconc[: a.five.maxR]).copy())
-    for _ in range(2):
-        episode_all()
+    m = ag[0].fr.five
     R = m.R
     assert mine.shape == (R, m.nant + 1), (mine.shape, R)
     assert (mine[:, :-1] == np.array(m.rant[:R])).all()

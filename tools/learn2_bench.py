@@ -30,8 +30,11 @@ frirl_amd.train_persistent(wp, wa, we, max_episodes=3, budget=64)
 del wp, wa, we
 prob, agent, envs = frirl_amd.demo_fresh_batch(env, E, 1024, dev, start_states=start)
 chunks = []
+stamps = []
 def on_chunk(i, live, conv):
     chunks.append(E if live is None else int(live.numel()))
+    if os.environ.get("STAMP"):
+        torch.cuda.synchronize(); stamps.append(time.perf_counter())
 torch.cuda.synchronize(); t0 = time.perf_counter()
 run = frirl_amd.train_persistent(prob, agent, envs, max_episodes=max_episodes, budget=budget, on_chunk=on_chunk)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
@@ -42,4 +45,5 @@ slots = w[0] * (14.4 * (A + 1) + 4.0 * (nant - 1)) + w[1] * (2.0 * nant + 10.4)
 print(json.dumps({"kernel": "learn_run", "env": env, "agents": E, "diversified_start": diversify, "budget": budget, "max_episodes": max_episodes, "opts": optv,
                   "wall_s": dt, "env_steps": total, "env_steps_per_s": total / dt, "launches": run.launches, "live_per_launch": chunks[:40],
                   "converged": int(run.conv.converged.sum()), "episodes_max": int(run.conv.episodes.max()), "rules_min": int(prob.nrules.min()), "rules_max": int(prob.nrules.max()),
+                  "launch_ms": [round((b - a) * 1e3, 2) for a, b in zip([t0] + stamps[:-1], stamps)][:40],
                   "visits_main": w[0], "visits_extra": w[1], "fp64_issue_frac": slots / dt / 3.93e13}))
