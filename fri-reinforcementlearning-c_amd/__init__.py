@@ -108,6 +108,7 @@ SIGNATURES = {
                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "frirl_hip_rollout_resident_rules": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frirl_hip_learn_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "frirl_hip_learn_plan": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "frirl_hip_learn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frirl_hip_learn_run": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
                                       C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -611,20 +612,29 @@ def train_persistent(problem, agent, envs, max_episodes=1000, budget=4096, on_ch
     if ws is None or ws.numel() * 8 < need:
         ws = torch.empty(((need + 7) // 8,), dtype=torch.float64, device=dev_)
         problem._learn_ws = ws
-    live = None
-    nlive = problem.E
+    order = torch.arange(problem.E, dtype=torch.int32, device=dev_)      # the agents that are still learning, next in line first
     launches = 0
-    while nlive > 0:
+    mean_rules = 0
+    while order.numel() > 0:
+        H, take = C.c_int32(), C.c_int32()
+        check(lib().frirl_hip_learn_plan(int(order.numel()), mean_rules, C.byref(H), C.byref(take)), "frirl_hip_learn_plan")
+        n = take.value
+        # agents of one wave walk as many rules as the largest rule base among them: neighbours in the launch get similar rule counts
+        live = order[:n]
+        live = live[torch.argsort(problem.nrules[live.long()], stable=True)].contiguous()
         check(lib().frirl_hip_learn_run(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), C.byref(conv.desc),
-                                        _ptr(live) if live is not None else None, nlive, budget, max_episodes, _ptr(work), _ptr(steps_total),
+                                        _ptr(live), n, budget, max_episodes, _ptr(work), _ptr(steps_total),
                                         _ptr(ws), ws.numel() * 8, _stream(stream)), "frirl_hip_learn_run")
         launches += 1
         conv.full |= (envs.status == UPD_FULL)
         if on_chunk is not None:
             on_chunk(launches, live, conv)
-        still = (conv.converged == 0) & (conv.episodes < max_episodes - 1)
-        live = still.nonzero().flatten().to(torch.int32).contiguous()      # one host round trip per launch: the number of live agents
-        nlive = int(live.numel())
+        lv = live.long()
+        still = (conv.converged[lv] == 0) & (conv.episodes[lv] < max_episodes - 1)
+        # one host round trip per launch (the number of agents left); the agents that had to wait go first next time
+        order = torch.cat([order[n:], live[still]])
+        if order.numel() > 0:
+            mean_rules = int(problem.nrules[order.long()].float().mean().item())
     if conv.full_envs:
         import warnings
         warnings.warn(f"frirl_amd.train_persistent: {conv.full_envs} of {problem.E} rule bases reached their capacity of {problem.maxR} rules: "

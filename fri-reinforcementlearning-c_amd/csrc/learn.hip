@@ -4,17 +4,49 @@
 using namespace frirl_host;
 int frirl_check_episode(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs, const char *who);
 
-// lanes per agent: the largest power of two that keeps every live agent resident at two waves per SIMD (2 ... 64): the fewer agents
-// are still learning, the more lanes each of them gets -- the chip stays full until fewer than 2048 agents are left
+static long learn_lanes()
+{
+    int cus = 256;
+    { int dev = 0, n = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n; }
+    return (long)cus * 4 * 2 * FRIRL_WAVE;              // two waves per SIMD (the kernels' register budget)
+}
+
+// lanes per agent for a launch of EXACTLY nlive agents: the largest power of two that keeps all of them resident (2 ... 64)
 static int learn_slices(int nlive)
 {
     { const int v = opts().learn_slices; if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v; }
-    int cus = 256;
-    { int dev = 0, n = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n; }
-    const long lanes = (long)cus * 4 * 2 * FRIRL_WAVE;
+    const long lanes = learn_lanes();
     int H = 2;
     while (H < 64 && (long)nlive * (2 * H) <= lanes) H *= 2;
     return H;
+}
+
+// How many of `nlive` agents that are still learning the next launch should take, and with how many lanes each.  A launch is at its
+// best when it fills the chip (two waves per SIMD); with H lanes per agent that takes lanes / H agents.  The more lanes an agent
+// has, the larger the share of a step that is not rule work (the environment's own dynamics, ~1000 instructions, and the butterfly),
+// so the plan maximises  occupancy(H) x rule-work share(H)  over H = 2 ... 64 -- and when more agents are alive than fill the chip at
+// that H, the launch takes the first lanes / H of them and the caller rotates the rest to the front of the next launch (every
+// launch full, instead of the half-empty launches a fixed assignment gives between two powers of two).
+extern "C" int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *slices, int32_t *agents_per_launch)
+{
+    if (nlive < 1 || !slices || !agents_per_launch) { set_error("frirl_hip_learn_plan: bad arguments"); return FRIRL_HIP_EINVAL; }
+    const long lanes = learn_lanes();
+    const double R = mean_rules > 0 ? mean_rules : 256;
+    int bestH = 2;
+    double best = -1.0;
+    for (int H = 2; H <= 64; H *= 2) {
+        const double occ = (double)nlive * H >= (double)lanes ? 1.0 : (double)nlive * H / (double)lanes;
+        const double rule_work = R * 93.0 / H;
+        int lg = 0;
+        for (int h = H; h > 1; h >>= 1) lg++;
+        const double score = occ * rule_work / (1000.0 + rule_work + 40.0 * lg);
+        if (score > best) { best = score; bestH = H; }
+    }
+    { const int v = opts().learn_slices; if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) bestH = v; }
+    const long cap = lanes / bestH;
+    *slices = bestH;
+    *agents_per_launch = (int32_t)((long)nlive < cap ? nlive : cap);
+    return FRIRL_HIP_OK;
 }
 
 extern "C" int frirl_hip_learn_supported(int32_t nant, int32_t U, int32_t A, int32_t p, int32_t env_kind)

@@ -14,10 +14,10 @@
 //   * groups are fed from an in-order queue (one atomic per wave and refill): a group whose episode ends takes the next
 //     environment at once, so the chip works on min(Q, lanes / H) environments at a time and the launch ends when the queue
 //     is empty, not when the slowest lane of every wave is done;
-//   * an episode that has used `cap` steps in a throughput phase (H = 4 / 16) is PARKED (state, reward so far, pending action)
-//     and finished by a later launch that gives it a whole wave (H = 64: per-step latency ~R/64 rules): the stragglers' serial
-//     chain runs at the latency form's speed instead of holding a throughput wave.  The follow-up launches choose themselves by
-//     the parked count they find on the device (no host round trip).
+//   * an episode that has used its stage's step budget is PARKED (state, reward so far, pending action) and continued by the next
+//     stage with more lanes: the survivors of a stage -- counted on the device, no host round trip -- get the lane-group size that
+//     fills the chip again (2 -> 4 -> ... -> 64 lanes per environment as their number halves), so the stragglers' serial chain runs at
+//     the latency form's speed (~R/64 rules per step) instead of holding throughput waves.
 // Sums: each lane adds its rules in index order, the H partials are added in butterfly order; every phase of one call runs a
 // different H, so an environment's Shepard sums change their rounding (not their value, <= 1e-13) when it is parked; WHICH
 // environments are parked depends only on their own trajectory and the static cap: results are deterministic.
@@ -30,10 +30,10 @@ namespace frirl {
 constexpr int RR_BLOCK = 256;
 
 struct RolloutCtl {            // device control block, zeroed before the first phase
-    unsigned next[4];          // queue head of each phase launch
-    unsigned parked;           // environments parked by the throughput phase
+    unsigned next[32];         // queue head of each launch
+    unsigned count[8];         // environments parked by stage s (the input of stage s + 1)
     unsigned too_big;          // 1: the rule base does not fit the LDS image -> the tiled kernel (shared.hip) runs instead
-    unsigned pad[2];
+    unsigned pad[7];
 };
 
 struct RolloutPark {           // environments parked by the throughput phase (SoA, capacity Q)
@@ -45,8 +45,9 @@ struct RolloutPark {           // environments parked by the throughput phase (S
 };
 
 struct RolloutPhase {
-    int from_parked;           // 0: items are the environment ids 0..Q-1 (fresh episodes); 1: items are parked records
-    unsigned lo, hi;           // from_parked: run only if lo < parked <= hi
+    int from_parked;           // 0: items are the environment ids 0..Q-1 (fresh episodes); 1: items are the records parked by stage - 1
+    int stage;                 // environments parked here are counted in RolloutCtl::count[stage]
+    unsigned lo, hi;           // from_parked: run only if lo < count[stage - 1] <= hi
     int cap;                   // steps per environment in this launch before it is parked (>= max_steps: never)
     int qslot;                 // which RolloutCtl::next
     int rps;                   // rules per column of the LDS image
@@ -121,7 +122,7 @@ template <int NANT, int NA, int KIND, int H, bool EXCL>
 __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
                                                                         const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
                                                                         const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro,
-                                                                        RolloutCtl *__restrict__ ctl, const RolloutPark park, const RolloutPhase ph)
+                                                                        RolloutCtl *__restrict__ ctl, const RolloutPark park, const RolloutPark dst, const RolloutPhase ph)
 {
     constexpr int NS = NANT - 1;
     extern __shared__ double col[];                       // [(NANT+1)][rps] rule base image, [2][NANT][U] tables (lds_tab), hash table, slot bytes
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl->too_big = 1u;
         return;
     }
-    const unsigned n_in = ph.from_parked ? ctl->parked : (unsigned)Q;
+    const unsigned n_in = ph.from_parked ? ctl->count[ph.stage - 1] : (unsigned)Q;
     if (ph.from_parked && !(n_in > ph.lo && n_in <= ph.hi)) return;
     double *tab_s = col + (size_t)(NANT + 1) * RPS;
     constexpr bool LT = KIND != FRIRL_HIP_ENV_CARTPOLE;   // small tables (41-point universes): universes and VE tables in LDS too
@@ -317,12 +318,12 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
             } else if (lsteps >= ph.cap) {                // a long episode: a later launch finishes it with a whole wave
                 active = false;
                 if (leader) {
-                    const unsigned w = atomicAdd(&ctl->parked, 1u);
-                    park.env[w] = qi;
-                    park.steps[w] = steps;
-                    park.total[w] = total;
-                    park.act[w] = pa;
-                    for (int k = 0; k < NS; k++) park.states[(size_t)w * NS + k] = states[k];
+                    const unsigned w = atomicAdd(&ctl->count[ph.stage], 1u);
+                    dst.env[w] = qi;
+                    dst.steps[w] = steps;
+                    dst.total[w] = total;
+                    dst.act[w] = pa;
+                    for (int k = 0; k < NS; k++) dst.states[(size_t)w * NS + k] = states[k];
                 }
             }
         }
@@ -345,29 +346,42 @@ int device_cus()
     return n;
 }
 
-template <int N, int NA, int KIND, int H>
+template <int N, int NA, int KIND, int H, bool EXCL>
 void launch_phase(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
-                  frirl::RolloutCtl *ctl, const frirl::RolloutPark &park, const frirl::RolloutPhase &ph, unsigned items_max, int wps, hipStream_t s)
+                  frirl::RolloutCtl *ctl, const frirl::RolloutPark &src, const frirl::RolloutPark &dst, const frirl::RolloutPhase &ph, unsigned items_max, int wps,
+                  hipStream_t s)
 {
-    const bool excl = ro->exclude_mask && ro->rule_slot;
     const size_t dyn = (size_t)(N + 1) * ph.rps * sizeof(double) + (KIND != FRIRL_HIP_ENV_CARTPOLE ? 2 * sizeof(double) * N * (size_t)t->U : 0) + sizeof(uint32_t) * (size_t)ph.ht +
-                       (excl ? (size_t)ph.rps : 0);
+                       (EXCL ? (size_t)ph.rps : 0);
     const long need = ((long)items_max * H + frirl::RR_BLOCK - 1) / frirl::RR_BLOCK;
     const long cap = (long)wps * device_cus();
     const dim3 grid((unsigned)(need < cap ? (need < 1 ? 1 : need) : cap));
-    if (excl)
-        hipLaunchKernelGGL((frirl::rollout_resident_kernel<N, NA, KIND, H, true>), grid, dim3(frirl::RR_BLOCK), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro, ctl, park, ph);
-    else
-        hipLaunchKernelGGL((frirl::rollout_resident_kernel<N, NA, KIND, H, false>), grid, dim3(frirl::RR_BLOCK), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro, ctl, park, ph);
+    hipLaunchKernelGGL((frirl::rollout_resident_kernel<N, NA, KIND, H, EXCL>), grid, dim3(frirl::RR_BLOCK), dyn, s, t->u, t->ve, t->U, b->rb, b->nrules, b->maxR, *ag, Q, *ro, ctl,
+                       src, dst, ph);
 }
 
+// the lane-group sizes compiled per shape: 3 actions 2 ... 64 (try-remove masks: 16 and 64 only, those launches are small), 21 actions 4 and 16
 template <int N, int NA, int KIND>
-void launch_phase_h(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
-                    frirl::RolloutCtl *ctl, const frirl::RolloutPark &park, const frirl::RolloutPhase &ph, unsigned items_max, int wps, hipStream_t s)
+void launch_phase_h(int H, bool excl, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                    frirl::RolloutCtl *ctl, const frirl::RolloutPark &src, const frirl::RolloutPark &dst, const frirl::RolloutPhase &ph, unsigned items_max, int wps,
+                    hipStream_t s)
 {
-    if constexpr (NA <= 8) { if (H == 64) { launch_phase<N, NA, KIND, 64>(t, b, ag, Q, ro, ctl, park, ph, items_max, wps, s); return; } }
-    if (H >= 16) launch_phase<N, NA, KIND, 16>(t, b, ag, Q, ro, ctl, park, ph, items_max, wps, s);
-    else launch_phase<N, NA, KIND, 4>(t, b, ag, Q, ro, ctl, park, ph, items_max, wps, s);
+#define GO(HH, EX) launch_phase<N, NA, KIND, HH, EX>(t, b, ag, Q, ro, ctl, src, dst, ph, items_max, wps, s)
+    if constexpr (NA <= 8) {
+        if (excl) { if (H >= 64) GO(64, true); else GO(16, true); return; }
+        switch (H) {
+            case 2: GO(2, false); break;
+            case 4: GO(4, false); break;
+            case 8: GO(8, false); break;
+            case 16: GO(16, false); break;
+            case 32: GO(32, false); break;
+            default: GO(64, false); break;
+        }
+    } else {
+        if (excl) { if (H >= 16) GO(16, true); else GO(4, true); }
+        else { if (H >= 16) GO(16, false); else GO(4, false); }
+    }
+#undef GO
 }
 
 }  // namespace
@@ -382,8 +396,14 @@ extern "C" int frirl_hip_rollout_resident_rules(int32_t nant, int32_t A, int32_t
     return (40 * 1024) / ((nant + 1) * 8 + 1 + 8) / 64 * 64;      // image + slot byte + 2 hash slots per rule in <= 40 KiB
 }
 
-// Returns 1 when the resident phases were enqueued (*ctl_out: control block whose too_big flag tells the tiled kernel, launched
-// after them by the caller when maxR exceeds the LDS image, whether it has to run), 0 when the shape is not covered.
+// Returns 1 when the resident stages were enqueued (*too_big_flag: set on the device when the rule base does not fit the LDS image --
+// the caller then launches the tiled kernel behind them, which runs only in that case), 0 when the shape is not covered.
+//
+// Stages (3 actions, no try-remove masks): every environment starts in stage 0 with as many lanes as keep ALL of them resident at two
+// waves per SIMD (2 for 65 536 environments); an episode that has used the stage's step budget is parked, and the next stage gives the
+// survivors -- counted on the device, no host round trip -- the lane-group size that fills the chip again (the launch whose range
+// holds the count runs, the others return at once).  Budgets: max_steps / 12, / 8, / 6 cumulative, then to the end: on the acrobot
+// demo 45 %, 10 % and 1.5 % of the episodes survive them.  Which environments are parked where depends only on their own trajectory.
 int frirl_rollout_resident(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
                            hipStream_t s, const unsigned **too_big_flag, void **workspace)
 {
@@ -395,61 +415,83 @@ int frirl_rollout_resident(const frirl_hip_tables *t, const frirl_hip_rulebases 
     const int NS = t->nant - 1;
     const int rps_full = (b->maxR + 63) / 64 * 64;
     const int rps = rps_full < cap_rules ? rps_full : cap_rules;
-    // workspace: control block + park lists, stream-ordered
+    const bool excl = ro->exclude_mask && ro->rule_slot;
+    // workspace: control block + two park lists (stages alternate between them), stream-ordered
     const size_t q8 = ((size_t)Q + 1) / 2 * 2;
-    const size_t bytes = 64 + q8 * (sizeof(int32_t) * 3 + sizeof(double) * (NS + 1));
+    const size_t list_bytes = q8 * (sizeof(int32_t) * 3 + sizeof(double) * (NS + 1));
+    const size_t ctl_bytes = (sizeof(frirl::RolloutCtl) + 63) / 64 * 64;
     char *ws = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&ws), bytes, s) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    (void)hipMemsetAsync(ws, 0, 64, s);
+    if (hipMallocAsync(reinterpret_cast<void **>(&ws), ctl_bytes + 2 * list_bytes, s) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    (void)hipMemsetAsync(ws, 0, ctl_bytes, s);
     frirl::RolloutCtl *ctl = reinterpret_cast<frirl::RolloutCtl *>(ws);
-    frirl::RolloutPark park;
-    park.states = reinterpret_cast<double *>(ws + 64);
-    park.total = park.states + q8 * NS;
-    park.env = reinterpret_cast<int32_t *>(park.total + q8);
-    park.steps = park.env + q8;
-    park.act = park.steps + q8;
-
-    const Options &o = opts();
-    int HA = Q <= 2048 ? 64 : (Q <= 16384 ? 16 : 4);
-    if (o.rollout_slices == 4 || o.rollout_slices == 16 || o.rollout_slices == 64) HA = o.rollout_slices;
-    if (ag->A > 8 && HA == 64) HA = 16;                     // many actions: the butterfly over 64 lanes would outweigh 3 rules per lane
-    const int wps = (o.rollout_wps >= 1 && o.rollout_wps <= 4) ? o.rollout_wps : 2;
-    int cap = ag->max_steps;
-    if (HA != 64 && !(ag->A > 8 && HA == 16)) {
-        cap = ag->max_steps / 6;
-        if (cap < 64) cap = 64;
-        if (o.rollout_cap > 0) cap = o.rollout_cap;
+    frirl::RolloutPark list[2];
+    for (int i = 0; i < 2; i++) {
+        char *base = ws + ctl_bytes + (size_t)i * list_bytes;
+        list[i].states = reinterpret_cast<double *>(base);
+        list[i].total = list[i].states + q8 * NS;
+        list[i].env = reinterpret_cast<int32_t *>(list[i].total + q8);
+        list[i].steps = list[i].env + q8;
+        list[i].act = list[i].steps + q8;
     }
-    if (cap >= ag->max_steps) cap = ag->max_steps > 0 ? ag->max_steps : 1;
-    const bool parks = cap < ag->max_steps;
-
+    const Options &o = opts();
+    const int wps = (o.rollout_wps >= 1 && o.rollout_wps <= 4) ? o.rollout_wps : 2;
+    const long lanes = (long)device_cus() * 4 * wps * FRIRL_WAVE;
     frirl::RolloutPhase ph = {};
     ph.rps = rps;
     ph.ht = 64;
     while (ph.ht < 2 * rps) ph.ht *= 2;
-    ph.cap = cap;
-    ph.qslot = 0;
-#define PHASE(HH, items)                                                                                                        \
-    do {                                                                                                                        \
-        if (t->nant == 3) launch_phase_h<3, 3, FRIRL_HIP_ENV_MOUNTAINCAR>(HH, t, b, ag, Q, ro, ctl, park, ph, items, wps, s);    \
-        else if (ag->A == 3) launch_phase_h<5, 3, FRIRL_HIP_ENV_ACROBOT>(HH, t, b, ag, Q, ro, ctl, park, ph, items, wps, s);    \
-        else launch_phase_h<5, 21, FRIRL_HIP_ENV_CARTPOLE>(HH, t, b, ag, Q, ro, ctl, park, ph, items, wps, s);                  \
+    int qslot = 0;
+#define PHASE(HH, items, SRC, DST)                                                                                                                 \
+    do {                                                                                                                                           \
+        ph.qslot = qslot++;                                                                                                                        \
+        if (t->nant == 3) launch_phase_h<3, 3, FRIRL_HIP_ENV_MOUNTAINCAR>(HH, excl, t, b, ag, Q, ro, ctl, SRC, DST, ph, items, wps, s);             \
+        else if (ag->A == 3) launch_phase_h<5, 3, FRIRL_HIP_ENV_ACROBOT>(HH, excl, t, b, ag, Q, ro, ctl, SRC, DST, ph, items, wps, s);             \
+        else launch_phase_h<5, 21, FRIRL_HIP_ENV_CARTPOLE>(HH, excl, t, b, ag, Q, ro, ctl, SRC, DST, ph, items, wps, s);                           \
     } while (0)
-    PHASE(HA, (unsigned)Q);
-    if (parks) {
-        // the parked episodes, finished by the launch whose range holds their number (the others return at once)
-        const int HL = ag->A > 8 ? 16 : 64;                 // latency form
-        ph.from_parked = 1;
-        ph.cap = ag->max_steps;
-        ph.qslot = 1; ph.lo = 0u; ph.hi = 2048u;
-        PHASE(HL, (unsigned)(Q < 2048 ? Q : 2048));
-        if (Q > 2048) {
-            ph.qslot = 2; ph.lo = 2048u; ph.hi = HA == 4 ? 16384u : 0xffffffffu;
-            PHASE(16, (unsigned)(Q < 16384 || HA != 4 ? Q : 16384));
+    const int never = ag->max_steps > 0 ? ag->max_steps : 1;
+    if (ag->A > 8 || excl || (long)Q * 64 <= lanes) {
+        // 21 actions / try-remove replays / few environments: one lane-group size; many environments of 21 actions park the long episodes once
+        int HA = (long)Q * 64 <= lanes ? 64 : ((long)Q * 16 <= lanes * 2 ? 16 : 4);
+        if (o.rollout_slices == 4 || o.rollout_slices == 16 || o.rollout_slices == 64) HA = o.rollout_slices;
+        if (ag->A > 8 && HA == 64) HA = 16;                 // the butterfly over 64 lanes would outweigh 3 rules per lane
+        int cap = never;
+        if (HA == 4 && !excl) {
+            cap = ag->max_steps / 6 < 64 ? 64 : ag->max_steps / 6;
+            if (o.rollout_cap > 0) cap = o.rollout_cap;
+            if (cap > never) cap = never;
         }
-        if (Q > 16384 && HA == 4) {
-            ph.qslot = 3; ph.lo = 16384u; ph.hi = 0xffffffffu;
-            PHASE(4, (unsigned)Q);
+        ph.from_parked = 0; ph.stage = 0; ph.cap = cap;
+        PHASE(HA, (unsigned)Q, list[0], list[0]);
+        if (cap < never) {
+            ph.from_parked = 1; ph.stage = 1; ph.cap = never;
+            ph.lo = 0u; ph.hi = (unsigned)(lanes / 16);
+            PHASE(16, (unsigned)((long)Q < lanes / 16 ? Q : lanes / 16), list[0], list[1]);
+            ph.lo = (unsigned)(lanes / 16); ph.hi = 0xffffffffu;
+            PHASE(4, (unsigned)Q, list[0], list[1]);
+        }
+    } else {
+        // the staged form
+        const int ms = ag->max_steps;
+        int budget[4] = {ms / 12, ms / 8 - ms / 12, ms / 6 - ms / 8, never};
+        if (o.rollout_cap > 0) { budget[0] = o.rollout_cap; budget[1] = budget[2] = o.rollout_cap / 2 > 0 ? o.rollout_cap / 2 : 1; }
+        int nstages = 4;
+        if (budget[0] < 16 || budget[1] < 8 || budget[2] < 8) { nstages = 1; budget[0] = never; }      // short episodes: nothing to stage
+        int H0 = 2;
+        while (H0 < 64 && (long)Q * (2 * H0) <= lanes) H0 *= 2;
+        if (o.rollout_slices == 2 || o.rollout_slices == 4 || o.rollout_slices == 8 || o.rollout_slices == 16 || o.rollout_slices == 32 || o.rollout_slices == 64) H0 = o.rollout_slices;
+        ph.from_parked = 0; ph.stage = 0; ph.cap = nstages > 1 ? budget[0] : never;
+        PHASE(H0, (unsigned)Q, list[0], list[0]);
+        unsigned in_max = (unsigned)Q;                       // upper bound of a stage's input
+        for (int st = 1; st < nstages; st++) {
+            ph.from_parked = 1; ph.stage = st; ph.cap = st == nstages - 1 ? never : budget[st];
+            const frirl::RolloutPark &src = list[(st - 1) & 1], &dst = list[st & 1];
+            for (int H = 64; H >= 2; H /= 2) {               // the launch whose range holds the survivors' number runs
+                const long fit = lanes / H;                  // environments that fill the chip at H lanes each
+                ph.lo = H == 64 ? 0u : (unsigned)(fit / 2 < 0xffffffffL ? fit / 2 : 0xffffffffL);
+                ph.hi = H == 2 ? 0xffffffffu : (unsigned)fit;
+                if (ph.lo >= in_max) continue;               // cannot happen: fewer environments than its range starts at
+                PHASE(H, (unsigned)((long)in_max < fit || H == 2 ? in_max : fit), src, dst);
+            }
         }
     }
 #undef PHASE

@@ -346,6 +346,11 @@ int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_ruleb
  * Decisions follow the oracle exactly on the demos (tests/test_hip_learn.py); interpolated Q within the 1e-6 contract (per-lane sums in
  * descending rule order, slices added in butterfly order). */
 int frirl_hip_learn_supported(int32_t nant, int32_t U, int32_t A, int32_t p, int32_t env_kind);
+/* How many of the `nlive` agents that are still learning the next frirl_hip_learn_run should take (*agents_per_launch <= nlive) and
+ * with how many lanes each (*slices): the launch that fills the chip at the lane-group size with the best product of occupancy and
+ * rule-work share (mean_rules: mean rule count of the live agents, 0 = unknown).  When fewer agents fit than are alive, the caller
+ * rotates: the ones left out go first in the next launch. */
+int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *slices, int32_t *agents_per_launch);
 size_t frirl_hip_learn_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
 int frirl_hip_learn_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
                         const frirl_hip_convergence *conv, const int32_t *live, int32_t nlive, int32_t budget_steps, int32_t max_episodes,
