@@ -13,10 +13,13 @@ each (E*R rule-distance evaluations, distances materialised as the reference's f
 BASELINE.json's metric "rule-distance evals/sec (rules x envs)".  Default workload = the north-star shape on one GPU
 (BASELINE.json configs[3] per GPU): acrobot tables (nant 5, U 41), 65 536 rules x 8 192 environments.  The second half
 of the metric, env-steps/sec, is the "env_steps" leg (fused do_action + reward + quantise + greedy sweep + SARSA update
-per environment); "learning" = E agents learn the demo from the reference's initial rule base to convergence
-(per-episode reward statistics all-reduced); "evaluation" = greedy roll-outs on one shared rule base; "other_configs"
-= the same two timed legs on BASELINE's other configurations (cfg2, cfg3, cfg5; N = 1 only); "cpu_baseline" = the
-genuine reference on the host cores (rank 0, N = 1, time-boxed).
+per environment); "learning" / "learning_diversified" = 65 536 agents per GPU learn the demo from the reference's initial
+rule base until every rule base is complete (replicas of the demo / one start state per agent; the job's report all-reduced
+per launch), with a COUNTED FP64-issue roofline (rule visits accumulated by the kernel); "evaluation" = greedy roll-outs of
+65 536 environments on one shared rule base, counted the same way; "other_configs" = the first two legs on BASELINE's other
+configurations (cfg2, cfg3, cfg5; N = 1 only); "cpu_baseline" = the genuine reference on the host cores (rank 0, N = 1,
+time-boxed).  Every timed leg is followed, outside the timed region, by a PARITY GATE (tests/gates.py): sampled environments
+against the oracle -- the run exits non-zero on a mismatch.
 
 roofline.achieved / frac are PHYSICAL: the bytes the timed kernel moves (compressed layout: 2*nant B of 16-bit
 universe indices read + 8 B distance written per evaluation) / the average launch time from
@@ -300,7 +303,7 @@ class Bench:
             pass
         return {"evals_per_s_rank": evals * steps / dt, "wall_s": dt, "exact_hits_rank": nhits, "parity_gate": gate}, roof
 
-    def env_steps_leg(self, w, prob, agent, envs, nsteps, warmup):
+    def env_steps_leg(self, w, prob, agent, envs, nsteps, warmup, name=None):
         """The metric's second half: whole environment steps (do_action, reward, quantise, greedy sweep, SARSA update)."""
         import frirl_amd
         torch = self.torch
@@ -322,7 +325,7 @@ class Bench:
                "moved_bytes_per_step": moved, "moved_GBps": moved / (ems * 1e-3) / 1e9, "moved_frac": moved / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "contract_bytes_per_step": float(E) * (2.0 * R * (nant + 1) * 8 + R * 8),    # SURVEY 8d U2 (the reference's three sweeps, f64)
                "rule_action_evals_per_s": float(E) * R * (w["A"] + 1) / (ems * 1e-3),
-               "fp64_issue": fp64_issue(E, R, nant, w["A"], ems),
+               "fp64_issue": fp64_issue(E, R, nant, w["A"], ems, name),
                "stats_allreduce": {"envs": st.envs, "mean_reward": st.mean_reward, "mean_rules": st.mean_rules, "steps_sum": st.steps_sum,
                                    "episodes_done": st.success, "reward_min": st.reward_min, "reward_max": st.reward_max},
                "last_step_outcomes_rank0": dict(zip(["inactive", "exact", "spread", "inserted", "skipped", "full"], status)),
@@ -336,7 +339,7 @@ class Bench:
 FP64_VECTOR_PEAK_TFLOPS = 78.6        # MI355X FP64 vector peak (FMA = 2 flop): 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x 2
 
 
-def fp64_issue(E, R, nant, A, ms):
+def fp64_issue(E, R, nant, A, ms, name=None):
     """FP64-issue roofline of the fused step.  Algorithmic slots per rule (one slot = one FP64 vector instruction of one lane;
     v_rsq_f64 issues in 3.4 slots, profiles/r02_valu_cost.txt): per conclusion (A greedy + 1 pending) 2 for the squared distance,
     3.4 + 7 for the Shepard weight (rsq + series + power, sweeps.h: shepard_series), 2 for the two sums = 14.4; plus the state part
@@ -344,7 +347,18 @@ def fp64_issue(E, R, nant, A, ms):
     slots_per_rule = 14.4 * (A + 1) + 2.0 * (nant - 1) + 2.0 * (nant - 1)
     peak = FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0          # lane-instructions per second
     achieved = float(E) * R * slots_per_rule / (ms * 1e-3)
-    return {"slots_per_rule": slots_per_rule, "achieved_lane_instr_per_s": achieved, "peak_lane_instr_per_s": peak, "frac": achieved / peak,
+    counted = None
+    try:        # the counter-derived figure beside the slot model: SQ_INSTS_VALU of this kernel from a committed PMC pass
+        cv = json.load(open(os.path.join(ROOT, "profiles", "valu.json"))).get(name)
+        if cv:
+            lane_instr = cv["insts_valu"] * 64.0 * (float(E) / cv["envs"])
+            counted = {"lane_instr_per_launch": lane_instr, "lane_instr_per_s": lane_instr / (ms * 1e-3), "frac": lane_instr / (ms * 1e-3) / peak,
+                       "kernel": cv["kernel"], "source": cv["source"],
+                       "note": "SQ_INSTS_VALU x 64 from the committed PMC pass / THIS run's launch time: every VALU instruction (FP64, integer, address) counts once"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"slots_per_rule": slots_per_rule, "achieved_lane_instr_per_s": achieved, "peak_lane_instr_per_s": peak, "frac": achieved / peak, "counted": counted,
+            "how": "frac = slot MODEL (algorithmic FP64 slots of the fused sweep / launch time / peak); counted = the same launch priced by the SQ_INSTS_VALU counter",
             "peak_source": "FP64 vector 78.6 TFLOP/s (half the FP32 vector peak of MI355X_MICROARCH.md: 16 lanes per clock and SIMD at 2.4 GHz) = 3.93e13 lane-instructions/s; a v_fma_f64 stream alone reaches 0.82 of it (profiles/r02_valu_cost.txt)"}
 
 
@@ -477,6 +491,16 @@ def learning_and_evaluation(B, w, world, rank):
         rsteps, rrew, rsucc, _ = one.rollout_shared(eagent, Qn, start_states=ss)
     B.sync_all()
     edt = D.max_over_ranks(time.perf_counter() - t0, device) / reps
+    # a stream of evaluation calls: two HIP streams, calls alternating between them, so that the tail of one call (a few long episodes on
+    # a handful of waves) overlaps the bulk of the next -- the call itself is unchanged (stream-ordered, no host round trip)
+    s2 = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    B.sync_all()
+    t0 = time.perf_counter()
+    for i in range(2 * reps):
+        with torch.cuda.stream(s2[i & 1]):
+            one.rollout_shared(eagent, Qn, start_states=ss, stream=s2[i & 1])
+    B.sync_all()
+    pdt = D.max_over_ranks(time.perf_counter() - t0, device) / (2 * reps)
     Rone = int(one.nrules[0].item())
     et = torch.tensor([float(rsteps.sum().item()), float((rsucc == 1).sum().item())], dtype=torch.float64, device=device)
     if world > 1:
@@ -490,7 +514,10 @@ def learning_and_evaluation(B, w, world, rank):
                           "fp64_issue": issue_record(sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)), edt,
                                                      {"rule_visits": sweeps * Rone, "slots_per_visit": 14.4 * A + 2.0 * (nant - 1),
                                                       "counted_from": "steps[] returned by the kernel: one greedy sweep over the rule base per step + one per episode start"}),
-                          "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates; average of 5 calls"}
+                          "pipelined": {"value": et[0].item() / pdt, "unit": "env-steps/s", "wall_s_per_call": pdt,
+                                        "fp64_issue_frac": sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)) / pdt / (FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0),
+                                        "how": "10 calls alternating between two HIP streams: one call's straggler tail overlaps the next call's bulk"},
+                          "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates; value = average of 5 back-to-back calls on one stream"}
     return legs
 
 
@@ -585,7 +612,7 @@ def main():
         dist.all_reduce(nhits)
     env_leg = None
     if agent is not None and not args.no_env_steps:
-        env_leg = B.env_steps_leg(w, prob, agent, envs, args.env_steps, min(args.warmup, 3))
+        env_leg = B.env_steps_leg(w, prob, agent, envs, args.env_steps, min(args.warmup, 3), args.workload)
     del prob, agent, envs, x
     torch.cuda.empty_cache()
 
@@ -608,9 +635,9 @@ def main():
             ox = make_queries(oprob, device, seed=0)
             oval, oroof = B.rule_distance_leg(name, ow, oprob, ox, max(args.steps // 2, 10), 3)
             rec = {"config": {"nant": ow["nant"], "universe_len": ow["U"], "rules_per_env": ow["R"], "envs_per_gpu": ow["E"]},
-                   "value": oval["evals_per_s_rank"], "unit": "evals/s", "roofline": oroof}
+                   "value": oval["evals_per_s_rank"], "unit": "evals/s", "roofline": oroof, "parity_gate": oval["parity_gate"]}
             if oagent is not None and not args.no_env_steps:
-                rec["env_steps"] = B.env_steps_leg(ow, oprob, oagent, oenvs, max(args.env_steps // 2, 5), 2)
+                rec["env_steps"] = B.env_steps_leg(ow, oprob, oagent, oenvs, max(args.env_steps // 2, 5), 2, name)
                 rec["env_steps"].pop("stats_allreduce", None)
             rec["wall_s_incl_setup"] = round(time.perf_counter() - t0, 1)
             others[name] = rec

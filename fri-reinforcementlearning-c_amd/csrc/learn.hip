@@ -39,7 +39,7 @@ extern "C" int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *
         const double rule_work = R * 93.0 / H;
         int lg = 0;
         for (int h = H; h > 1; h >>= 1) lg++;
-        const double score = occ * rule_work / (1000.0 + rule_work + 40.0 * lg);
+        const double score = occ * rule_work / (5200.0 + rule_work + 40.0 * lg);     // 5200: the measured per-step share that does not shrink with H (profiles/r03b_kernels_after_trims.jsonl)
         if (score > best) { best = score; bestH = H; }
     }
     { const int v = opts().learn_slices; if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) bestH = v; }
@@ -63,7 +63,7 @@ static size_t learn_entries(int nlive, int maxR, int H)
 {
     const int EPW = FRIRL_WAVE / H;
     const size_t tiles = ((size_t)nlive + EPW - 1) / EPW, njmax = ((size_t)maxR + H - 1) / H;
-    return tiles * njmax * 64;
+    return tiles * (njmax + frirl::LR_PADROWS) * 64;
 }
 
 extern "C" size_t frirl_hip_learn_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A)

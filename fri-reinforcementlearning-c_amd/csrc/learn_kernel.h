@@ -31,6 +31,7 @@ namespace frirl {
 #define LEARN_UR 2      // rules fetched per batch, two batches in flight
 #endif
 constexpr int LR_BLOCK = 256;
+constexpr int LR_PADROWS = 16;     // rule rows in front of every tile that nothing consumes: the prefetch of the descending walk may run past row 0
 constexpr int LR_WPB = LR_BLOCK / FRIRL_WAVE;
 
 struct LearnArgs {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void learn_import_kernel(const LearnArgs la, i
             q = la.rb[((size_t)e * (NANT + 1) + NANT) * la.maxR + r];
             p = prev_rconc[(size_t)e * la.maxR + r];
         }
-        const size_t o = ((size_t)tile * la.njmax + j) * 64 + lane;
+        const size_t o = ((size_t)tile * (la.njmax + LR_PADROWS) + LR_PADROWS + j) * 64 + lane;
 #pragma unroll
         for (int x = 0; x < W; x++) la.Ti[o * W + x] = w[x];
         la.Tq[o] = q;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void learn_export_kernel(const LearnArgs la, i
     for (int j = threadIdx.x / 64; j < njw; j += 4) {
         const int r = j * H + h;
         if (r < R) {
-            const size_t o = ((size_t)tile * la.njmax + j) * 64 + lane;
+            const size_t o = ((size_t)tile * (la.njmax + LR_PADROWS) + LR_PADROWS + j) * 64 + lane;
             la.rb[((size_t)e * (nant + 1) + nant) * la.maxR + r] = la.Tq[o];
             prev_rconc[(size_t)e * la.maxR + r] = la.Tp[o];
         }
@@ -123,11 +124,15 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     constexpr int FPW = Packed<BITS>::FPW, W = Packed<BITS>::words(NANT);
     constexpr int UR = LEARN_UR;                                        // rules fetched per batch, two batches in flight
     using RecI = typename std::conditional<W == 1, uint32_t, typename std::conditional<W == 2, uint2, uint4>::type>::type;
-    extern __shared__ double tab_s[];                                         // [NANT][U] VE tables, then [NANT][U] universes (if lds_u)
+    // STATIC LDS, so that every address is a compile-time constant: a table entry is read at  8 * index  with the table row's address
+    // as the instruction's immediate offset (no base register to add).  Tables have a fixed row stride of 64 entries (6-bit indices).
+    static_assert(BITS == 6, "the LDS tables are laid out for 6-bit universe indices (universes of <= 64 points)");
+    constexpr int TS = 64;
+    constexpr bool LU = KIND != FRIRL_HIP_ENV_CARTPOLE;                          // small tables: the universes in LDS too
+    constexpr int NCOLD = 2 * NS + 2 * NANT + 3 + 4;                          // cold per-agent state parked during every sweep (see below)
+    __shared__ double tab_s[(LU ? 2 : 1) * NANT * TS];
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
-    __shared__ double udiv[NANT];                                             // FIVEInit.c:244-248, once instead of per observation
-    // cold per-agent state, parked here for the duration of every sweep (see below): 2 NS + 2 NANT + 3 doubles and 8 words per group
-    constexpr int NCOLD = 2 * NS + 2 * NANT + 3 + 4;
+    __shared__ double udiv[8];                                                // FIVEInit.c:244-248, once instead of per observation
     __shared__ double cold_s[LR_WPB * (FRIRL_WAVE / H) * NCOLD];
     const int U = la.U, maxR = la.maxR;
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
@@ -136,17 +141,17 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     const int slot = tile * EPW + il;
     const bool exists = tile < la.tiles && slot < la.nlive;
     const int e = exists ? (la.live ? la.live[slot] : slot) : 0;
-    for (int i = threadIdx.x; i < NANT * U; i += LR_BLOCK) tab_s[i] = la.ve[i];
-    constexpr bool LU = KIND != FRIRL_HIP_ENV_CARTPOLE;                          // small tables: the universes in LDS too
-    if (LU) for (int i = threadIdx.x; i < NANT * U; i += LR_BLOCK) tab_s[NANT * U + i] = la.u[i];
+    for (int i = threadIdx.x; i < NANT * U; i += LR_BLOCK) tab_s[(i / U) * TS + i % U] = la.ve[i];
+    if (LU) for (int i = threadIdx.x; i < NANT * U; i += LR_BLOCK) tab_s[NANT * TS + (i / U) * TS + i % U] = la.u[i];
     for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += LR_BLOCK) grid_s[i] = ag.grid_values[i];
     __syncthreads();
     const double *ves = tab_s, *us;
-    if constexpr (LU) us = tab_s + NANT * U; else us = la.u;
-    if ((int)threadIdx.x < NANT) udiv[threadIdx.x] = universe_div(us + (size_t)threadIdx.x * U, U);
+    if constexpr (LU) us = tab_s + NANT * TS; else us = la.u;
+    const int USTR = LU ? TS : U;                                             // row stride of `us`
+    if ((int)threadIdx.x < NANT) udiv[threadIdx.x] = universe_div(us + (size_t)threadIdx.x * USTR, U);
     __syncthreads();
-    auto observe = [&](int k, double x) { const double *uni = us + (size_t)k * U; return ves[(size_t)k * U + snap_index(uni, U, x, udiv[k])]; };
-    const size_t tbase = (size_t)(tile < la.tiles ? tile : 0) * la.njmax * 64;
+    auto observe = [&](int k, double x) { const double *uni = us + (size_t)k * USTR; return ves[(size_t)k * TS + snap_index(uni, U, x, udiv[k])]; };
+    const size_t tbase = ((size_t)(tile < la.tiles ? tile : 0) * (la.njmax + LR_PADROWS) + LR_PADROWS) * 64;
     const RecI *Ti_l = reinterpret_cast<const RecI *>(la.Ti) + tbase + lane;      // this lane's rules: element j at [j * 64]
     double *Tq_l = la.Tq + tbase + lane, *Tp_l = la.Tp + tbase + lane;
     RecI *Ti_g = reinterpret_cast<RecI *>(la.Ti) + tbase + il * H;                // the group's rule r: [(r / H) * 64 + r % H]
@@ -161,8 +166,10 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
         if constexpr (W == 1) { w[0] = x; } else if constexpr (W == 2) { w[0] = x.x; w[1] = x.y; } else { w[0] = x.x; w[1] = x.y; w[2] = x.z; if constexpr (W > 3) w[3] = x.w; }
 #pragma unroll
         for (int k = 0; k < NANT; k++) {
-            const uint32_t idx = (w[k / FPW] >> (BITS * (k % FPW))) & ((1u << BITS) - 1u);
-            c[k] = ves[k * U + (int)idx];
+            constexpr uint32_t FM = ((1u << BITS) - 1u) << 3;
+            const int sh = BITS * (k % FPW);
+            const uint32_t off = (sh >= 3 ? (w[k / FPW] >> (sh - 3)) : (w[k / FPW] << (3 - sh))) & FM;     // 8 * index
+            c[k] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ves + k * TS) + off);
         }
     };
     // f(r, VE values of rule r, its consequent) for this lane's rules r = j H + h < R, from the highest j down; NEEDQ: load consequents
@@ -171,12 +178,13 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
         if (nj <= 0) return;
         RecI ia[UR], ib[UR];
         double qa[UR], qb[UR];
-        auto fetch = [&](RecI(&xi)[UR], double(&xq)[UR], int jtop) {        // rules jtop, jtop - 1, ..., jtop - UR + 1 (clamped at 0)
+        auto fetch = [&](RecI(&xi)[UR], double(&xq)[UR], int jtop) {        // rules jtop, jtop - 1, ..., jtop - UR + 1: ONE address per array, the
+            const RecI *pi = Ti_l + (long)jtop * 64;                          // rest are immediate offsets; rows below 0 are the tile's padding
+            const double *pq = Tq_l + (long)jtop * 64;
 #pragma unroll
             for (int t = 0; t < UR; t++) {
-                const int j = jtop - t < 0 ? 0 : jtop - t;
-                xi[t] = Ti_l[(size_t)j * 64];
-                xq[t] = needq ? Tq_l[(size_t)j * 64] : 0.0;
+                xi[t] = pi[-t * 64];
+                xq[t] = needq ? pq[-t * 64] : 0.0;
             }
         };
         auto consume = [&](const RecI(&xi)[UR], const double(&xq)[UR], int jtop) {
@@ -363,9 +371,9 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
 #pragma unroll
                         for (int k = 0; k < NANT; k++) {
                             rant[k] = check_possible_states(q_ant[k], grid_s + k * FRIRL_HIP_MAX_GRID, ag.grid_len[k]);   // :146-170
-                            const double *uni = us + (size_t)k * U;
+                            const double *uni = us + (size_t)k * USTR;
                             idx3[k] = snap_index(uni, U, rant[k], udiv[k]);
-                            ve3[k] = ves[(size_t)k * U + idx3[k]];
+                            ve3[k] = ves[(size_t)k * TS + idx3[k]];
                             same = same && (ve3[k] == ve1[k]);
                         }
                         double v3 = vs1, w3 = ws1;                                                      // :370 (same VE point => same sums)
@@ -504,12 +512,11 @@ inline void launch_learn(const frirl_hip_tables *t, const frirl_hip_rulebases *b
     constexpr int EPW = FRIRL_WAVE / H, W = frirl::Packed<BITS>::words(N);
     la.tiles = (la.nlive + EPW - 1) / EPW;
     la.njmax = (b->maxR + H - 1) / H;
-    const size_t n = (size_t)la.tiles * la.njmax * 64;
+    const size_t n = (size_t)la.tiles * (la.njmax + frirl::LR_PADROWS) * 64;
     char *ws = reinterpret_cast<char *>(la.Ti);
     la.Tq = reinterpret_cast<double *>(ws + ((n * W * sizeof(uint32_t) + 15) / 16) * 16);
     la.Tp = la.Tq + n;
-    const size_t tab = sizeof(double) * N * (size_t)t->U;
-    const size_t dyn = tab + (KIND != FRIRL_HIP_ENV_CARTPOLE ? tab : 0);
+    const size_t dyn = 0;
     hipLaunchKernelGGL((frirl::learn_import_kernel<N, BITS>), dim3(la.tiles), dim3(256), 0, s, la, H, cv->prev_rconc);
     const int blocks = (la.tiles + frirl::LR_WPB - 1) / frirl::LR_WPB;
     hipLaunchKernelGGL((frirl::learn_kernel<N, NA, KIND, H, BITS, WPS>), dim3(blocks), dim3(frirl::LR_BLOCK), dyn, s, la, *ag, *ev, *cv);

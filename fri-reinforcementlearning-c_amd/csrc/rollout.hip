@@ -69,12 +69,14 @@ __device__ __forceinline__ uint32_t hash_mix(uint32_t hsh, double x)
     return hsh ^ (hsh >> 15);
 }
 
+// The LDS image of the rule base is rule-major: rule r occupies the NANT + 1 consecutive doubles col[r * (NANT + 1) + k] (antecedent VE
+// values, then the consequent) -- one address per rule and 16-byte reads with immediate offsets in the sweep.
 template <int NANT>
-__device__ __forceinline__ bool rule_equals(const double *col, int RPS, int r, const double (&key)[NANT])
+__device__ __forceinline__ bool rule_equals(const double *col, int, int r, const double (&key)[NANT])
 {
     bool eq = true;
 #pragma unroll
-    for (int k = 0; k < NANT; k++) eq = eq && (col[k * RPS + r] == key[k]);
+    for (int k = 0; k < NANT; k++) eq = eq && (col[r * (NANT + 1) + k] == key[k]);
     return eq;
 }
 
@@ -84,7 +86,7 @@ __device__ __forceinline__ void hash_insert(uint32_t *tab, int ht, const double 
     double key[NANT];
     uint32_t hsh = 0u;
 #pragma unroll
-    for (int k = 0; k < NANT; k++) { key[k] = col[k * RPS + r]; hsh = hash_mix(hsh, key[k]); }
+    for (int k = 0; k < NANT; k++) { key[k] = col[r * (NANT + 1) + k]; hsh = hash_mix(hsh, key[k]); }
     for (int i = 0; i < ht; i++) {
         const uint32_t slot = (hsh + (uint32_t)i) & (uint32_t)(ht - 1);
         const uint32_t cur = atomicCAS(&tab[slot], HT_EMPTY, (uint32_t)r);
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
                                                                         RolloutCtl *__restrict__ ctl, const RolloutPark park, const RolloutPark dst, const RolloutPhase ph)
 {
     constexpr int NS = NANT - 1;
-    extern __shared__ double col[];                       // [(NANT+1)][rps] rule base image, [2][NANT][U] tables (lds_tab), hash table, slot bytes
+    extern __shared__ __attribute__((aligned(16))) double col[];   // [rps][NANT+1] rule base image (rule-major), [2][NANT][U] tables, hash table, slot bytes
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
     const int RPS = ph.rps;
     const int R = nrules[0];
@@ -141,9 +143,9 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
     uint8_t *slot_s = reinterpret_cast<uint8_t *>(hash_s + ph.ht);
     const int nj = (R + H - 1) / H;                       // rules per lane; the padding rules of the last round weigh exactly 0
     for (int i = threadIdx.x; i < (NANT + 1) * RPS; i += RR_BLOCK) {
-        const int k = i / RPS, r = i - k * RPS;
+        const int k = i / RPS, r = i - k * RPS;          // coalesced reads of the canonical columns, transposed into the rule-major image
         // padding: first antecedent 1e150 away (squared distance ~1e300, its weight underflows to 0), consequent 0
-        col[i] = (r < R) ? rb[(size_t)k * maxR + r] : (k == 0 ? 1.0e150 : 0.0);
+        col[r * (NANT + 1) + k] = (r < R) ? rb[(size_t)k * maxR + r] : (k == 0 ? 1.0e150 : 0.0);
     }
     if (EXCL) for (int r = threadIdx.x; r < RPS; r += RR_BLOCK) slot_s[r] = (r < R) ? ro.rule_slot[r] : (uint8_t)255;
     for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += RR_BLOCK) grid_s[i] = ag.grid_values[i];
@@ -260,11 +262,12 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
 #pragma unroll 2
             for (int j = 0; j < nj; j++) {
                 const int r = j * H + h;
-                const double d0 = q[0] - col[r];
+                const double *rule = col + r * (NANT + 1);
+                const double d0 = q[0] - rule[0];
                 double s = d0 * d0;
 #pragma unroll
-                for (int k = 1; k < NS; k++) { const double d = q[k] - col[k * RPS + r]; s = __fma_rn(d, d, s); }
-                const double va = col[NS * RPS + r], cq = col[NANT * RPS + r];
+                for (int k = 1; k < NS; k++) { const double d = q[k] - rule[k]; s = __fma_rn(d, d, s); }
+                const double va = rule[NS], cq = rule[NANT];
                 if (EXCL) {                               // a removed rule weighs exactly 0 (same sums as the compacted rule base)
                     const unsigned sl = slot_s[r];
                     s = (sl < 32u && ((mask >> sl) & 1u)) ? NO_RULE_STATE_PART : s;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
             int pa = 0;
 #pragma unroll
             for (int a = 0; a < NA; a++) {
-                const double c = (sh[a] != FRIRL_HIP_NO_HIT) ? col[NANT * RPS + (int)sh[a]] : sv[a] / sw[a];
+                const double c = (sh[a] != FRIRL_HIP_NO_HIT) ? col[(int)sh[a] * (NANT + 1) + NANT] : sv[a] / sw[a];
                 if (a == 0 || bv < c) { bv = c; pa = a; }
             }
             bool ended = false;
@@ -330,6 +333,209 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
     }
 }
 
+
+// ---- the latency form: TWO waves per environment ---------------------------------------------------------------------------
+// An episode is a serial chain: step t + 1 needs the action chosen at step t.  With one wave per environment a step is the sum of two
+// halves that do not need each other's RESULT until the very end: the greedy sweep over the rules for the current observation
+// (hash probes, ~R / 64 rules per lane, butterfly, arg-max) and the environment's own dynamics for the next state (trig, divisions,
+// quantiser, universe snap) -- which depend on the action, but there are only A of them.  So the workgroup has two waves: the SWEEPER
+// picks the action for the current state while the STEPPER advances the environment for EVERY action in parallel lanes (lane a: action
+// a); after one barrier both take the chosen action's outcome from LDS.  A step costs the longer half plus a barrier instead of the
+// sum.  Used for the last stage of the staged roll-outs (the stragglers) and for launches of up to a few thousand environments (the
+// try-remove replays of the rule-base reduction).  Same arithmetic per value as the one-wave form: identical results.
+constexpr int RP_BLOCK = 2 * FRIRL_WAVE;
+
+template <int NANT>
+struct PairSpec {              // outcome of one speculative step (per action), double-buffered
+    double state[NANT - 1], q[NANT - 1], reward;
+    int success, pad;
+};
+
+template <int NANT, int NA, int KIND, bool EXCL>
+__global__ __launch_bounds__(RP_BLOCK, 4) void rollout_pair_kernel(const double *__restrict__ u, const double *__restrict__ ve, int U,
+                                                                   const double *__restrict__ rb, const int32_t *__restrict__ nrules, int maxR,
+                                                                   const frirl_hip_agent ag, int Q, const frirl_hip_rollout ro,
+                                                                   RolloutCtl *__restrict__ ctl, const RolloutPark park, const RolloutPhase ph)
+{
+    constexpr int NS = NANT - 1, H = FRIRL_WAVE;
+    extern __shared__ __attribute__((aligned(16))) double col[];   // image, tables, hash table, slot bytes: as rollout_resident_kernel
+    __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
+    __shared__ PairSpec<NANT> spec_s[2][NA];
+    __shared__ int act_s[2];
+    __shared__ unsigned item_s;
+    const int RPS = ph.rps;
+    const int R = nrules[0];
+    if (R > RPS) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->too_big = 1u;
+        return;
+    }
+    const unsigned n_in = ph.from_parked ? ctl->count[ph.stage - 1] : (unsigned)Q;
+    if (ph.from_parked && !(n_in > ph.lo && n_in <= ph.hi)) return;
+    double *tab_s = col + (size_t)(NANT + 1) * RPS;
+    constexpr bool LT = KIND != FRIRL_HIP_ENV_CARTPOLE;
+    uint32_t *hash_s = reinterpret_cast<uint32_t *>(tab_s + (LT ? 2 * NANT * U : 0));
+    uint8_t *slot_s = reinterpret_cast<uint8_t *>(hash_s + ph.ht);
+    const int nj = (R + H - 1) / H;
+    for (int i = threadIdx.x; i < (NANT + 1) * RPS; i += RP_BLOCK) {
+        const int k = i / RPS, r = i - k * RPS;
+        col[r * (NANT + 1) + k] = (r < R) ? rb[(size_t)k * maxR + r] : (k == 0 ? 1.0e150 : 0.0);
+    }
+    if (EXCL) for (int r = threadIdx.x; r < RPS; r += RP_BLOCK) slot_s[r] = (r < R) ? ro.rule_slot[r] : (uint8_t)255;
+    for (int i = threadIdx.x; i < NANT * FRIRL_HIP_MAX_GRID; i += RP_BLOCK) grid_s[i] = ag.grid_values[i];
+    if (LT) for (int i = threadIdx.x; i < NANT * U; i += RP_BLOCK) { tab_s[i] = ve[i]; tab_s[NANT * U + i] = u[i]; }
+    for (int i = threadIdx.x; i < ph.ht; i += RP_BLOCK) hash_s[i] = HT_EMPTY;
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += RP_BLOCK) hash_insert<NANT>(hash_s, ph.ht, col, RPS, r);
+    __syncthreads();
+    const double *ves, *us;
+    if constexpr (LT) { ves = tab_s; us = tab_s + NANT * U; } else { ves = ve; us = u; }
+    double udiv[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) udiv[k] = universe_div(us + (size_t)k * U, U);
+    auto observe = [&](int k, double x) { const double *uni = us + (size_t)k * U; return ves[(size_t)k * U + snap_index(uni, U, x, udiv[k])]; };
+
+    const int lane = threadIdx.x & (FRIRL_WAVE - 1);
+    const bool sweeper = threadIdx.x < FRIRL_WAVE;        // wave 0 sweeps, wave 1 steps the environment
+    const auto pk = pin_pow(PowC<NANT>());
+    double ave[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) ave[a] = ag.action_ve[a];
+
+    // next environment of the in-order queue.  The loop has ONE latch and it holds a barrier: thread 0's "store the results, take the
+    // next item" block must not become a second back edge -- the compiler then splits the loop in two and parks lane 0 outside the
+    // inner one, where the other lanes wait for an item nobody fetches (seen: a hang).
+    if (threadIdx.x == 0) item_s = atomicAdd(&ctl->next[ph.qslot], 1u);
+    __syncthreads();
+    unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)item_s);
+    __syncthreads();
+    while (item < n_in) {
+        double states[NS], q[NS], total = 0.0;
+        int qi, steps = 0, success = 0;
+        bool fresh;
+        if (ph.from_parked) {
+            // a parked episode knows its pending action: that step is taken here (both waves, same values), then the loop selects again
+            qi = park.env[item];
+            steps = park.steps[item];
+            total = park.total[item];
+            const double action = grid_s[NS * FRIRL_HIP_MAX_GRID + park.act[item]];
+            double s0[NS], cur[NS], qs[NS], r;
+#pragma unroll
+            for (int k = 0; k < NS; k++) s0[k] = park.states[(size_t)item * NS + k];
+            env_do_action(KIND, action, s0, cur);
+            env_get_reward(KIND, cur, r, success);
+            total = total + r;
+            env_quantize(KIND, NS, grid_s, ag.grid_len, ag.grid_div, cur, qs);
+#pragma unroll
+            for (int k = 0; k < NS; k++) { states[k] = cur[k]; q[k] = observe(k, qs[k]); }
+            steps++;
+            fresh = false;
+        } else {
+            qi = (int)item;
+#pragma unroll
+            for (int k = 0; k < NS; k++) { states[k] = ro.start_states ? ro.start_states[(size_t)qi * NS + k] : ag.values_def[k]; q[k] = observe(k, states[k]); }
+            fresh = true;
+        }
+        const uint32_t mask = (EXCL && ro.exclude_mask) ? ro.exclude_mask[qi] : 0u;
+        // `steps` transitions have been made; the state they led to needs its action unless the episode is over already
+        bool ended = (!fresh && success == 1) || steps >= ag.max_steps;
+        for (int it = 0; !ended; it++) {
+            const int buf = it & 1;
+            if (sweeper) {
+                // ---- frirl_get_best_action for the current observation (as rollout_resident_kernel with H = 64) ------------------
+                double sv[NA], sw[NA];
+                unsigned sh[NA];
+                double key[NANT];
+                uint32_t hs = 0u;
+#pragma unroll
+                for (int k = 0; k < NS; k++) { key[k] = q[k]; hs = hash_mix(hs, q[k]); }
+#pragma unroll
+                for (int a = 0; a < NA; a++) {
+                    key[NS] = ave[a];
+                    unsigned f = hash_lookup<NANT>(hash_s, ph.ht, col, RPS, hs, key);
+                    if (EXCL && f != FRIRL_HIP_NO_HIT) {
+                        const unsigned sl = slot_s[f];
+                        if (sl < 32u && ((mask >> sl) & 1u)) {
+                            unsigned g = FRIRL_HIP_NO_HIT;
+                            for (int r = (int)f + 1; r < R && g == FRIRL_HIP_NO_HIT; r++) {
+                                const unsigned s2 = slot_s[r];
+                                if (!(s2 < 32u && ((mask >> s2) & 1u)) && rule_equals<NANT>(col, RPS, r, key)) g = (unsigned)r;
+                            }
+                            f = g;
+                        }
+                    }
+                    sh[a] = f;
+                    sv[a] = 0.0; sw[a] = 0.0;
+                }
+#pragma unroll 2
+                for (int j = 0; j < nj; j++) {
+                    const int r = j * H + lane;
+                    const double *rule = col + r * (NANT + 1);
+                    const double d0 = q[0] - rule[0];
+                    double s = d0 * d0;
+#pragma unroll
+                    for (int k = 1; k < NS; k++) { const double d = q[k] - rule[k]; s = __fma_rn(d, d, s); }
+                    const double va = rule[NS], cq = rule[NANT];
+                    if (EXCL) {
+                        const unsigned sl = slot_s[r];
+                        s = (sl < 32u && ((mask >> sl) & 1u)) ? NO_RULE_STATE_PART : s;
+                    }
+#pragma unroll
+                    for (int a = 0; a < NA; a++) {
+                        const double e = ave[a] - va;
+                        const double d2 = __fma_rn(e, e, s);
+                        const double wi = shepard_w(d2, pk);
+                        sv[a] = __fma_rn(wi, cq, sv[a]);
+                        sw[a] = sw[a] + wi;
+                    }
+                }
+                group_sum_n<NA>(sv, H);
+                group_sum_n<NA>(sw, H);
+                double bv = 0.0;
+                int pa = 0;
+#pragma unroll
+                for (int a = 0; a < NA; a++) {
+                    const double c = (sh[a] != FRIRL_HIP_NO_HIT) ? col[(int)sh[a] * (NANT + 1) + NANT] : sv[a] / sw[a];
+                    if (a == 0 || bv < c) { bv = c; pa = a; }
+                }
+                pa = e_greedy(ag, pa, (uint32_t)qi, 0u, (uint32_t)steps);          // step index of the state the action is chosen for (:78 / :148)
+                if (lane == 0) act_s[buf] = pa;
+            } else if (lane < NA) {
+                // ---- the environment's step for EVERY action (lane a: action a), before anybody knows which one is taken --------
+                double cur[NS], qs[NS], r;
+                int succ;
+                env_do_action(KIND, grid_s[NS * FRIRL_HIP_MAX_GRID + lane], states, cur);                 // :97
+                env_get_reward(KIND, cur, r, succ);                                                      // :106
+                env_quantize(KIND, NS, grid_s, ag.grid_len, ag.grid_div, cur, qs);                       // :112
+                PairSpec<NANT> &o = spec_s[buf][lane];
+#pragma unroll
+                for (int k = 0; k < NS; k++) { o.state[k] = cur[k]; o.q[k] = observe(k, qs[k]); }
+                o.reward = r;
+                o.success = succ;
+            }
+            __syncthreads();
+            const PairSpec<NANT> &o = spec_s[buf][act_s[buf]];
+#pragma unroll
+            for (int k = 0; k < NS; k++) { states[k] = o.state[k]; q[k] = o.q[k]; }                      // :163-165
+            total = total + o.reward;                                                                    // :107
+            success = o.success;
+            steps++;                                                                                     // :174
+            fresh = false;
+            ended = success == 1 || steps >= ag.max_steps;                                               // :183, :86
+        }
+        if (threadIdx.x == 0) {
+            ro.steps[qi] = steps;
+            ro.reward[qi] = total;
+            if (ro.success) ro.success[qi] = success;
+            if (ro.final_states)
+                for (int k = 0; k < NS; k++) ro.final_states[(size_t)qi * NS + k] = states[k];
+            item_s = atomicAdd(&ctl->next[ph.qslot], 1u);
+        }
+        __syncthreads();
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)item_s);
+        __syncthreads();
+    }
+}
+
 }  // namespace frirl
 
 using namespace frirl_host;
@@ -360,6 +566,19 @@ void launch_phase(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const
                        src, dst, ph);
 }
 
+template <int N, int NA, int KIND, bool EXCL>
+void launch_pair(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
+                 frirl::RolloutCtl *ctl, const frirl::RolloutPark &src, const frirl::RolloutPhase &ph, unsigned items_max, hipStream_t s)
+{
+    const size_t dyn = (size_t)(N + 1) * ph.rps * sizeof(double) + (KIND != FRIRL_HIP_ENV_CARTPOLE ? 2 * sizeof(double) * N * (size_t)t->U : 0) + sizeof(uint32_t) * (size_t)ph.ht +
+                       (EXCL ? (size_t)ph.rps : 0);
+    const long per_cu = dyn > 0 ? (long)((150 * 1024) / (dyn + 4096)) : 8;      // workgroups a CU's LDS holds
+    const long cap = (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu)) * device_cus();
+    const long need = items_max < 1 ? 1 : (long)items_max;
+    hipLaunchKernelGGL((frirl::rollout_pair_kernel<N, NA, KIND, EXCL>), dim3((unsigned)(need < cap ? need : cap)), dim3(frirl::RP_BLOCK), dyn, s, t->u, t->ve, t->U, b->rb,
+                       b->nrules, b->maxR, *ag, Q, *ro, ctl, src, ph);
+}
+
 // the lane-group sizes compiled per shape: 3 actions 2 ... 64 (try-remove masks: 16 and 64 only, those launches are small), 21 actions 4 and 16
 template <int N, int NA, int KIND>
 void launch_phase_h(int H, bool excl, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, int Q, const frirl_hip_rollout *ro,
@@ -368,6 +587,16 @@ void launch_phase_h(int H, bool excl, const frirl_hip_tables *t, const frirl_hip
 {
 #define GO(HH, EX) launch_phase<N, NA, KIND, HH, EX>(t, b, ag, Q, ro, ctl, src, dst, ph, items_max, wps, s)
     if constexpr (NA <= 8) {
+        // a whole wave per environment: the two-wave form (sweeper + speculative stepper) -- unless a FRESH launch has more environments
+        // than its workgroups hold at once (each keeps its own LDS image): short replays in two rounds lose more than a step gains
+        const size_t pdyn = (size_t)(N + 1) * ph.rps * sizeof(double) + (KIND != FRIRL_HIP_ENV_CARTPOLE ? 2 * sizeof(double) * N * (size_t)t->U : 0) + sizeof(uint32_t) * (size_t)ph.ht + (excl ? (size_t)ph.rps : 0);
+        const long pcu = (long)((150 * 1024) / (pdyn + 4096));
+        const long pcap = (pcu < 1 ? 1 : (pcu > 8 ? 8 : pcu)) * device_cus();
+        if (H >= 64 && opts().rollout_pair != 0 && (ph.from_parked || (long)items_max <= pcap || opts().rollout_pair == 1)) {
+            if (excl) launch_pair<N, NA, KIND, true>(t, b, ag, Q, ro, ctl, src, ph, items_max, s);
+            else launch_pair<N, NA, KIND, false>(t, b, ag, Q, ro, ctl, src, ph, items_max, s);
+            return;
+        }
         if (excl) { if (H >= 64) GO(64, true); else GO(16, true); return; }
         switch (H) {
             case 2: GO(2, false); break;

@@ -38,6 +38,7 @@ static const OptName k_opts[] = {
     {"rollout_slices", "FRIRL_HIP_ROLLOUT_SLICES", &Options::rollout_slices, 0},
     {"rollout_resident", "FRIRL_HIP_ROLLOUT_RESIDENT", &Options::rollout_resident, -1},
     {"rollout_cap", "FRIRL_HIP_ROLLOUT_CAP", &Options::rollout_cap, 0},
+    {"rollout_pair", "FRIRL_HIP_ROLLOUT_PAIR", &Options::rollout_pair, -1},
     {"rollout_wps", "FRIRL_HIP_ROLLOUT_WPS", &Options::rollout_wps, 0},
     {"learn_slices", "FRIRL_HIP_LEARN_SLICES", &Options::learn_slices, 0},
     {"learn_persistent", "FRIRL_HIP_LEARN_PERSISTENT", &Options::learn_persistent, -1},
