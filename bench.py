@@ -491,16 +491,6 @@ def learning_and_evaluation(B, w, world, rank):
         rsteps, rrew, rsucc, _ = one.rollout_shared(eagent, Qn, start_states=ss)
     B.sync_all()
     edt = D.max_over_ranks(time.perf_counter() - t0, device) / reps
-    # a stream of evaluation calls: two HIP streams, calls alternating between them, so that the tail of one call (a few long episodes on
-    # a handful of waves) overlaps the bulk of the next -- the call itself is unchanged (stream-ordered, no host round trip)
-    s2 = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
-    B.sync_all()
-    t0 = time.perf_counter()
-    for i in range(2 * reps):
-        with torch.cuda.stream(s2[i & 1]):
-            one.rollout_shared(eagent, Qn, start_states=ss, stream=s2[i & 1])
-    B.sync_all()
-    pdt = D.max_over_ranks(time.perf_counter() - t0, device) / (2 * reps)
     Rone = int(one.nrules[0].item())
     et = torch.tensor([float(rsteps.sum().item()), float((rsucc == 1).sum().item())], dtype=torch.float64, device=device)
     if world > 1:
@@ -514,9 +504,6 @@ def learning_and_evaluation(B, w, world, rank):
                           "fp64_issue": issue_record(sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)), edt,
                                                      {"rule_visits": sweeps * Rone, "slots_per_visit": 14.4 * A + 2.0 * (nant - 1),
                                                       "counted_from": "steps[] returned by the kernel: one greedy sweep over the rule base per step + one per episode start"}),
-                          "pipelined": {"value": et[0].item() / pdt, "unit": "env-steps/s", "wall_s_per_call": pdt,
-                                        "fp64_issue_frac": sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)) / pdt / (FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0),
-                                        "how": "10 calls alternating between two HIP streams: one call's straggler tail overlaps the next call's bulk"},
                           "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates; value = average of 5 back-to-back calls on one stream"}
     return legs
 

@@ -168,6 +168,7 @@ struct Options {
     int rollout_pair;     // resident roll-out, one environment per wave: 0 = the one-wave form instead of sweeper + speculative stepper (FRIRL_HIP_ROLLOUT_PAIR)
     int rollout_wps;      // resident roll-out: persistent waves per SIMD, 1 or 2 (0 = 2)             (FRIRL_HIP_ROLLOUT_WPS)
     int learn_slices;     // persistent learner: lanes per agent 4 / 16 / 64, 0 = by the number of live agents (FRIRL_HIP_LEARN_SLICES)
+    int learn_alone;      // learner launch plan: cost factor (tenths) of a wave that has its SIMD to itself, 0 = 20 (FRIRL_HIP_LEARN_ALONE)
     int learn_persistent; // 0: frirl_hip_learn_supported answers no (callers fall back to one episode per launch) (FRIRL_HIP_LEARN_PERSISTENT)
     int multi_loopback;   // 1: frirl_hip_multi_create builds LOGICAL shards on the current device with the loop-back transport (tests) (FRIRL_HIP_MULTI_LOOPBACK)
     int mirror_sync;      // single-agent fused step: 1 = wait with hipStreamSynchronize instead of polling the completion flag (FRIRL_HIP_MIRROR_SYNC)

@@ -32,14 +32,24 @@ extern "C" int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *
     if (nlive < 1 || !slices || !agents_per_launch) { set_error("frirl_hip_learn_plan: bad arguments"); return FRIRL_HIP_EINVAL; }
     const long lanes = learn_lanes();
     const double R = mean_rules > 0 ? mean_rules : 256;
+    // time of one step of every live agent, per agent: a wave's step costs a fixed share (the environment's own dynamics, the update
+    // logic, the group's dependent loads: ~5200 instruction-equivalents, measured, profiles/r03b_kernels_after_trims.jsonl) plus its
+    // rules (~93 instructions each, R / H per lane) plus the butterfly; up to one wave per SIMD the waves run side by side, a lone wave
+    // paying `alone` (its stalls are not hidden: measured, a lone wave gets ~half the issue rate -- option learn_alone, in tenths, default 2.0:
+    // 0.85 / 0.75 / 0.73 / 0.70 / 0.69 s for 1.0 / 1.3 / 1.6 / 2.0 / 3.0 on the diversified acrobot run); beyond that they share the issue slots.
+    const double alone = opts().learn_alone > 0 ? 0.1 * opts().learn_alone : 2.0;
+    const double simds = (double)lanes / (2.0 * FRIRL_WAVE);
     int bestH = 2;
     double best = -1.0;
     for (int H = 2; H <= 64; H *= 2) {
-        const double occ = (double)nlive * H >= (double)lanes ? 1.0 : (double)nlive * H / (double)lanes;
-        const double rule_work = R * 93.0 / H;
         int lg = 0;
         for (int h = H; h > 1; h >>= 1) lg++;
-        const double score = occ * rule_work / (5200.0 + rule_work + 40.0 * lg);     // 5200: the measured per-step share that does not shrink with H (profiles/r03b_kernels_after_trims.jsonl)
+        const double wave_step = 5200.0 + R * 93.0 / H + 40.0 * lg;
+        double waves = (double)nlive * H / FRIRL_WAVE;
+        double agents = nlive;
+        if (waves > 2.0 * simds) { waves = 2.0 * simds; agents = (double)lanes / H; }      // the launch takes what fills the chip
+        const double share = waves / simds > alone ? waves / simds : alone;
+        const double score = agents / (wave_step * share);                                    // agent-steps per unit of time
         if (score > best) { best = score; bestH = H; }
     }
     { const int v = opts().learn_slices; if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) bestH = v; }

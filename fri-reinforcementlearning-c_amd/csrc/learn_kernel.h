@@ -173,20 +173,31 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
         }
     };
     // f(r, VE values of rule r, its consequent) for this lane's rules r = j H + h < R, from the highest j down; NEEDQ: load consequents
-    auto for_slice = [&](int R, bool needq, auto &&f) {
-        const int nj = (R - h + H - 1) / H;                                   // this lane's rules: j = 0 .. nj - 1
-        if (nj <= 0) return;
-        RecI ia[UR], ib[UR];
-        double qa[UR], qb[UR];
-        auto fetch = [&](RecI(&xi)[UR], double(&xq)[UR], int jtop) {        // rules jtop, jtop - 1, ..., jtop - UR + 1: ONE address per array, the
-            const RecI *pi = Ti_l + (long)jtop * 64;                          // rest are immediate offsets; rows below 0 are the tile's padding
-            const double *pq = Tq_l + (long)jtop * 64;
+    // rules jtop, jtop - 1, ..., jtop - UR + 1 of this lane: ONE address per array, the rest are immediate offsets; rows below 0 are
+    // the tile's padding (loaded, never consumed)
+    auto fetch = [&](RecI(&xi)[UR], double(&xq)[UR], int jtop, bool needq) {
+        const RecI *pi = Ti_l + (long)jtop * 64;
+        const double *pq = Tq_l + (long)jtop * 64;
 #pragma unroll
-            for (int t = 0; t < UR; t++) {
-                xi[t] = pi[-t * 64];
-                xq[t] = needq ? pq[-t * 64] : 0.0;
-            }
-        };
+        for (int t = 0; t < UR; t++) {
+            xi[t] = pi[-t * 64];
+            xq[t] = needq ? pq[-t * 64] : 0.0;
+        }
+    };
+    // The FIRST batch of a walk is requested by slice_prefetch -- well before the walk starts (the main sweep's: before the environment's
+    // own dynamics; the weighted spread's: before the butterfly and the update logic), so that the ~2 us of a global load are not spent
+    // waiting at the top of every walk: with one or two waves per SIMD nothing else would hide them.
+    struct Pref { RecI i[UR]; double q[UR]; int jt; };
+    auto slice_prefetch = [&](int R, bool needq) {
+        Pref p;
+        p.jt = (R - h + H - 1) / H - 1;                                       // this lane's rules: j = 0 .. jt (jt < 0: none)
+        if (p.jt < -1) p.jt = -1;
+        fetch(p.i, p.q, p.jt, needq);
+        return p;
+    };
+    auto for_slice_from = [&](Pref &p, bool needq, auto &&f) {
+        RecI ib[UR];
+        double qb[UR];
         auto consume = [&](const RecI(&xi)[UR], const double(&xq)[UR], int jtop) {
 #pragma unroll
             for (int t = 0; t < UR; t++) {
@@ -194,15 +205,18 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                 if (j >= 0) { double c[NANT]; decode(xi[t], c); f(j * H + h, c, xq[t]); }
             }
         };
-        int jt = nj - 1;
-        fetch(ia, qa, jt);
+        int jt = p.jt;
         while (jt >= 0) {
-            fetch(ib, qb, jt - UR);
-            consume(ia, qa, jt);
-            fetch(ia, qa, jt - 2 * UR);
+            fetch(ib, qb, jt - UR, needq);
+            consume(p.i, p.q, jt);
+            fetch(p.i, p.q, jt - 2 * UR, needq);
             consume(ib, qb, jt - UR);
             jt -= 2 * UR;
         }
+    };
+    auto for_slice = [&](int R, bool needq, auto &&f) {
+        Pref p = slice_prefetch(R, needq);
+        for_slice_from(p, needq, f);
     };
     auto group_or = [&](bool v) -> bool {
         const unsigned long long b = __ballot(v ? 1 : 0);
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     while (__any(active ? 1 : 0)) {
         double cur[NS], cur_q[NANT], ve1[NANT], ve2[NS], reward = 0.0;
         int success = 0;
+        Pref pmain = slice_prefetch(active ? R : 0, true);                    // in flight while the environment steps
         if (active) {
             if (begin) {                                                      // frirl_episode.c:46-48: q_states = states = start state
 #pragma unroll
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
 #pragma unroll
         for (int i = 0; i < NC; i++) { sv[i] = 0.0; sw[i] = 0.0; sh[i] = FRIRL_HIP_NO_HIT; }
         if (active) {
-            for_slice(R, true, [&](int r, const double (&c)[NANT], double cq) {
+            for_slice_from(pmain, true, [&](int r, const double (&c)[NANT], double cq) {
                 const double e0 = ve2[0] - c[0], g0 = ve1[0] - c[0];
                 double s2 = e0 * e0, s1 = g0 * g0;
 #pragma unroll
@@ -306,6 +321,9 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             });
             wmain += R;
         }
+        // the weighted spread, if this step's update takes that branch, walks the rules once more (indices only): its first batch is
+        // requested now and arrives during the butterfly and the update logic
+        Pref pspread = slice_prefetch(active ? R : 0, false);
         if (H > 1) {                                                          // the H rule slices of every conclusion, a few conclusions at a time
             constexpr int CH = 4;
 #pragma unroll
@@ -442,7 +460,8 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                                 if (ev.spread_R) ev.spread_R[e] = R;
                             }
                             const double iws = 1.0 / ws1;
-                            for_slice(R, false, [&](int r, const double (&c)[NANT], double) {           // K6 + K7, every lane its own rules
+                            // (an append between the prefetch and here would have left through `finished`: R is unchanged)
+                            for_slice_from(pspread, false, [&](int r, const double (&c)[NANT], double) {   // K6 + K7, every lane its own rules
                                 const double d0 = ve1[0] - c[0];
                                 double s = d0 * d0;
 #pragma unroll

@@ -41,6 +41,7 @@ static const OptName k_opts[] = {
     {"rollout_pair", "FRIRL_HIP_ROLLOUT_PAIR", &Options::rollout_pair, -1},
     {"rollout_wps", "FRIRL_HIP_ROLLOUT_WPS", &Options::rollout_wps, 0},
     {"learn_slices", "FRIRL_HIP_LEARN_SLICES", &Options::learn_slices, 0},
+    {"learn_alone", "FRIRL_HIP_LEARN_ALONE", &Options::learn_alone, 0},
     {"learn_persistent", "FRIRL_HIP_LEARN_PERSISTENT", &Options::learn_persistent, -1},
     {"multi_loopback", "FRIRL_HIP_MULTI_LOOPBACK", &Options::multi_loopback, 0},
     {"no_many", "FRIRL_HIP_NO_MANY", &Options::no_many, 0},

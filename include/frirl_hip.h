@@ -97,7 +97,7 @@ int frirl_hip_device_count(void);                 /* number of visible gfx950 de
 int frirl_hip_device_info(int device, char *name, int name_len, int32_t *cus, int64_t *hbm_bytes);
 
 /* Experiment / test switches by name: "no_uidx" (1 = ignore the 16-bit index mirror), "rd_unroll", "rd_chunk", "rd_nt",
- * "rd_persist", "rd_order", "step_wave", "step_track", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices", "rollout_resident", "rollout_cap", "rollout_pair", "rollout_wps", "learn_slices", "learn_persistent", "multi_loopback", "no_many", "mirror_sync".  Their defaults
+ * "rd_persist", "rd_order", "step_wave", "step_track", "lanes_slices", "lanes_wpe", "rollout_group", "rollout_slices", "rollout_resident", "rollout_cap", "rollout_pair", "rollout_wps", "learn_slices", "learn_alone", "learn_persistent", "multi_loopback", "no_many", "mirror_sync".  Their defaults
  * (the shipped configuration) are read ONCE from the matching FRIRL_HIP_<NAME> environment variable, never per launch;
  * results do not depend on any of them (only the kernel variant / launch shape does). */
 int frirl_hip_set_option(const char *name, int value);
