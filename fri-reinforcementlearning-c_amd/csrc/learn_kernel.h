@@ -184,9 +184,9 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             xq[t] = needq ? pq[-t * 64] : 0.0;
         }
     };
-    // The FIRST batch of a walk is requested by slice_prefetch -- well before the walk starts (the main sweep's: before the environment's
-    // own dynamics; the weighted spread's: before the butterfly and the update logic), so that the ~2 us of a global load are not spent
-    // waiting at the top of every walk: with one or two waves per SIMD nothing else would hide them.
+    // The FIRST batch of the main sweep is requested by slice_prefetch before the environment's own dynamics, so that its global loads are
+    // in flight meanwhile (measured neutral at two waves per SIMD: 0.476 vs 0.483 counted; the same for the weighted spread's walk cost
+    // four spilled registers and was dropped -- profiles/r03c_learn_prefetch.jsonl).
     struct Pref { RecI i[UR]; double q[UR]; int jt; };
     auto slice_prefetch = [&](int R, bool needq) {
         Pref p;
@@ -321,9 +321,6 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             });
             wmain += R;
         }
-        // the weighted spread, if this step's update takes that branch, walks the rules once more (indices only): its first batch is
-        // requested now and arrives during the butterfly and the update logic
-        Pref pspread = slice_prefetch(active ? R : 0, false);
         if (H > 1) {                                                          // the H rule slices of every conclusion, a few conclusions at a time
             constexpr int CH = 4;
 #pragma unroll
@@ -460,8 +457,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                                 if (ev.spread_R) ev.spread_R[e] = R;
                             }
                             const double iws = 1.0 / ws1;
-                            // (an append between the prefetch and here would have left through `finished`: R is unchanged)
-                            for_slice_from(pspread, false, [&](int r, const double (&c)[NANT], double) {   // K6 + K7, every lane its own rules
+                            for_slice(R, false, [&](int r, const double (&c)[NANT], double) {           // K6 + K7, every lane its own rules
                                 const double d0 = ve1[0] - c[0];
                                 double s = d0 * d0;
 #pragma unroll
