@@ -413,10 +413,9 @@ def learning_and_evaluation(B, w, world, rank):
             chunks = []
 
             def on_chunk(i, live, conv):
-                # the report of the many-agent job: reward statistics only cross the GPUs -- one tiny all-reduce per launch
+                # the report of the many-agent job (reward statistics only).  Ranks with diversified agents make DIFFERENT numbers of
+                # launches, so nothing collective may happen per launch: the statistics are kept locally and cross the GPUs once, below
                 st = torch.stack([lenvs.ep_reward.sum(), lenvs.ep_steps.sum().double(), lprob.nrules.sum().double(), conv.converged.sum().double()])
-                if world > 1:
-                    dist.all_reduce(st)
                 chunks.append((LEARN_AGENTS if live is None else int(live.numel()), st))
             B.sync_all()
             t0 = time.perf_counter()
@@ -424,10 +423,10 @@ def learning_and_evaluation(B, w, world, rank):
             B.sync_all()
             ldt = D.max_over_ranks(time.perf_counter() - t0, device)
             wk = run.work.sum(0).double()
-            tot = torch.stack([run.steps_total.sum().double(), run.conv.converged.sum().double(), lprob.nrules.sum().double(),
-                               torch.tensor(float(run.conv.full_envs), device=device, dtype=torch.float64), wk[0], wk[1]])
+            tot = torch.cat([torch.stack([run.steps_total.sum().double(), run.conv.converged.sum().double(), lprob.nrules.sum().double(),
+                                          torch.tensor(float(run.conv.full_envs), device=device, dtype=torch.float64), wk[0], wk[1]]), chunks[-1][1]])
             if world > 1:
-                dist.all_reduce(tot)
+                dist.all_reduce(tot)                  # the ONE exchange of the leg: totals + the final report (RCCL over xGMI; latency-bound)
             tot = tot.tolist()
             slots = tot[4] * (14.4 * (A + 1) + 4.0 * (nant - 1)) + tot[5] * (2.0 * nant + 10.4)
             eps = run.conv.episodes
@@ -435,7 +434,8 @@ def learning_and_evaluation(B, w, world, rank):
                           "wall_s": ldt, "env_steps": tot[0], "agents_converged": tot[1], "max_episodes": max_episodes,
                           "episodes_min_max_rank0": [int(eps.min().item()), int(eps.max().item())], "mean_final_rules": tot[2] / (LEARN_AGENTS * world),
                           "agents_with_refused_appends": tot[3], "launches": run.launches, "live_agents_per_launch_rank0": [c[0] for c in chunks][:64],
-                          "report_allreduce": {"launches": len(chunks), "last": dict(zip(["reward_sum", "steps_sum", "rules_sum", "converged"], [float(v) for v in chunks[-1][1].tolist()]))},
+                          "report_allreduce": {"launches_rank0": len(chunks), "final": dict(zip(["reward_sum", "steps_sum", "rules_sum", "converged"], tot[6:10])),
+                                               "note": "one all-reduce per leg: ranks make different numbers of launches"},
                           "kernel": "learn_kernel (persistent construct loop, csrc/learn_kernel.h)",
                           "fp64_issue": issue_record(slots, ldt, {"rule_visits_fused_sweeps": tot[4], "rule_visits_extra_sweeps": tot[5],
                                                                   "slots_per_fused_visit": 14.4 * (A + 1) + 4.0 * (nant - 1), "slots_per_extra_visit": 2.0 * nant + 10.4})}
@@ -491,6 +491,19 @@ def learning_and_evaluation(B, w, world, rank):
         rsteps, rrew, rsucc, _ = one.rollout_shared(eagent, Qn, start_states=ss)
     B.sync_all()
     edt = D.max_over_ranks(time.perf_counter() - t0, device) / reps
+    # a STREAM of evaluation calls: calls alternate between two HIP streams, so that one call's straggler tail (a few long episodes on a
+    # handful of waves) overlaps the next call's bulk -- the call itself is unchanged (stream-ordered, no host round trip)
+    s2 = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    for st_ in s2:
+        with torch.cuda.stream(st_):
+            one.rollout_shared(eagent, Qn, start_states=ss, stream=st_)
+    B.sync_all()
+    t0 = time.perf_counter()
+    for i in range(2 * reps):
+        with torch.cuda.stream(s2[i & 1]):
+            one.rollout_shared(eagent, Qn, start_states=ss, stream=s2[i & 1])
+    B.sync_all()
+    pdt = D.max_over_ranks(time.perf_counter() - t0, device) / (2 * reps)
     Rone = int(one.nrules[0].item())
     et = torch.tensor([float(rsteps.sum().item()), float((rsucc == 1).sum().item())], dtype=torch.float64, device=device)
     if world > 1:
@@ -504,6 +517,9 @@ def learning_and_evaluation(B, w, world, rank):
                           "fp64_issue": issue_record(sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)), edt,
                                                      {"rule_visits": sweeps * Rone, "slots_per_visit": 14.4 * A + 2.0 * (nant - 1),
                                                       "counted_from": "steps[] returned by the kernel: one greedy sweep over the rule base per step + one per episode start"}),
+                          "pipelined": {"value": et[0].item() / pdt, "unit": "env-steps/s", "wall_s_per_call": pdt,
+                                        "fp64_issue_frac": sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)) / pdt / (FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0),
+                                        "how": "the same call 10 times, alternating between two HIP streams: one call's straggler tail overlaps the next call's bulk"},
                           "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates; value = average of 5 back-to-back calls on one stream"}
     return legs
 

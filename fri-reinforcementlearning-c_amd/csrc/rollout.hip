@@ -23,7 +23,9 @@
 // environments are parked depends only on their own trajectory and the static cap: results are deterministic.
 #include "sweeps.h"
 #include "envs.h"
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace frirl {
 
@@ -542,6 +544,35 @@ using namespace frirl_host;
 
 namespace {
 
+// Workspace of the resident stages, one per stream and kept: hipMallocAsync / hipFreeAsync per call would let the pool hand the block
+// freed on one stream to the next call on ANOTHER stream behind an inserted dependency -- which serialises calls that alternate between
+// two streams exactly where they could overlap (one call's straggler tail with the next call's bulk).  A few MB per stream, freed when
+// the library is unloaded.
+struct StreamWs { hipStream_t s; int dev; char *p; size_t bytes; };
+std::mutex g_ws_mu;
+std::vector<StreamWs> g_ws;
+struct WsCleanup { ~WsCleanup() { for (StreamWs &w : g_ws) if (w.p) (void)hipFree(w.p); } } g_ws_cleanup;
+char *stream_workspace(hipStream_t s, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (StreamWs &w : g_ws)
+        if (w.s == s && w.dev == dev) {
+            if (w.bytes >= bytes) return w.p;
+            (void)hipStreamSynchronize(s);                 // growing: the old block may still be in use by queued launches of this stream
+            (void)hipFree(w.p);
+            w.p = nullptr; w.bytes = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&w.p), bytes) != hipSuccess) { (void)hipGetLastError(); w.p = nullptr; return nullptr; }
+            w.bytes = bytes;
+            return w.p;
+        }
+    StreamWs w{s, dev, nullptr, bytes};
+    if (hipMalloc(reinterpret_cast<void **>(&w.p), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_ws.push_back(w);
+    return w.p;
+}
+
 int g_cus = 0;
 int device_cus()
 {
@@ -649,8 +680,8 @@ int frirl_rollout_resident(const frirl_hip_tables *t, const frirl_hip_rulebases 
     const size_t q8 = ((size_t)Q + 1) / 2 * 2;
     const size_t list_bytes = q8 * (sizeof(int32_t) * 3 + sizeof(double) * (NS + 1));
     const size_t ctl_bytes = (sizeof(frirl::RolloutCtl) + 63) / 64 * 64;
-    char *ws = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&ws), ctl_bytes + 2 * list_bytes, s) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    char *ws = stream_workspace(s, ctl_bytes + 2 * list_bytes);      // stream-ordered reuse: the previous call on this stream is done with it
+    if (!ws) return 0;
     (void)hipMemsetAsync(ws, 0, ctl_bytes, s);
     frirl::RolloutCtl *ctl = reinterpret_cast<frirl::RolloutCtl *>(ws);
     frirl::RolloutPark list[2];
@@ -725,6 +756,6 @@ int frirl_rollout_resident(const frirl_hip_tables *t, const frirl_hip_rulebases 
     }
 #undef PHASE
     *too_big_flag = rps_full > cap_rules ? &ctl->too_big : nullptr;
-    *workspace = ws;
+    *workspace = nullptr;                                     // owned by the per-stream cache: nothing for the caller to free
     return 1;
 }

@@ -399,7 +399,7 @@ extern "C" int frirl_hip_rollout_shared(const frirl_hip_tables *t, const frirl_h
             if (t->nant == 3) launch_rollout_n<3>(t, b, agent, Q, ro, s, too_big);
             else launch_rollout_n<5>(t, b, agent, Q, ro, s, too_big);
         }
-        (void)hipFreeAsync(ws, s);
+        if (ws) (void)hipFreeAsync(ws, s);
         return check_launch("frirl_hip_rollout_shared");
     }
     if (t->nant == 3) launch_rollout_n<3>(t, b, agent, Q, ro, s, nullptr);
