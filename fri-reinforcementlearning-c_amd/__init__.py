@@ -612,6 +612,7 @@ def train_persistent(problem, agent, envs, max_episodes=1000, budget=4096, on_ch
     if ws is None or ws.numel() * 8 < need:
         ws = torch.empty(((need + 7) // 8,), dtype=torch.float64, device=dev_)
         problem._learn_ws = ws
+    problem._learn_progress = (steps_total, work)                         # for on_chunk callbacks that report per-launch progress
     order = torch.arange(problem.E, dtype=torch.int32, device=dev_)      # the agents that are still learning, next in line first
     launches = 0
     mean_rules = 0

@@ -33,6 +33,7 @@ namespace frirl {
 constexpr int LR_BLOCK = 256;
 constexpr int LR_PADROWS = 16;     // rule rows in front of every tile that nothing consumes: the prefetch of the descending walk may run past row 0
 constexpr int LR_WPB = LR_BLOCK / FRIRL_WAVE;
+constexpr int LR_MW = 16;          // 32-bit words of spread-candidate flags per lane (one bit per rule of the lane's slice: 512 rules)
 
 struct LearnArgs {
     const double *u, *ve;        // tables [nant][U]
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
     __shared__ double udiv[8];                                                // FIVEInit.c:244-248, once instead of per observation
     __shared__ double cold_s[LR_WPB * (FRIRL_WAVE / H) * NCOLD];
+    __shared__ uint32_t mask_s[LR_MW * LR_BLOCK];                             // [word][thread]: spread candidates of the sweep (see `thr`)
+    static_assert(32 % (2 * UR) == 0, "a flag word is filled by whole loop iterations");
     const int U = la.U, maxR = la.maxR;
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
     const int il = lane / H, h = lane % H;
@@ -195,28 +198,49 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
         fetch(p.i, p.q, p.jt, needq);
         return p;
     };
-    auto for_slice_from = [&](Pref &p, bool needq, auto &&f) {
+    // FLAGS: f returns a word whose sign bit says "this rule may carry a significant weight of the pending conclusion"; the bits are
+    // collected MSB-first, 32 rules per word, in mask_s[word][thread] (walk position q = jt0 - j -> word q / 32, bit 31 - q % 32)
+    auto for_slice_from = [&](Pref &p, bool needq, auto &&f, auto flags) {
+        constexpr bool FL = decltype(flags)::value;
         RecI ib[UR];
         double qb[UR];
+        uint32_t cmask = 0u;
         auto consume = [&](const RecI(&xi)[UR], const double(&xq)[UR], int jtop) {
 #pragma unroll
             for (int t = 0; t < UR; t++) {
                 const int j = jtop - t;
-                if (j >= 0) { double c[NANT]; decode(xi[t], c); f(j * H + h, c, xq[t]); }
+                if constexpr (FL) {
+                    uint32_t hi = 0u;
+                    if (j >= 0) { double c[NANT]; decode(xi[t], c); hi = f(j * H + h, c, xq[t]); }
+                    cmask = __builtin_amdgcn_alignbit(cmask, hi, 31);       // (cmask << 1) | (hi >> 31)
+                } else {
+                    if (j >= 0) { double c[NANT]; decode(xi[t], c); f(j * H + h, c, xq[t]); }
+                }
             }
         };
         int jt = p.jt;
+        const int jt0 = jt, jtm = jt & 31;
         while (jt >= 0) {
             fetch(ib, qb, jt - UR, needq);
             consume(p.i, p.q, jt);
             fetch(p.i, p.q, jt - 2 * UR, needq);
             consume(ib, qb, jt - UR);
             jt -= 2 * UR;
+            if constexpr (FL) {
+                if ((jt & 31) == jtm) {                                        // 32 more rules walked: a full word
+                    const int wd = ((jt0 - jt) >> 5) - 1;
+                    if (wd < LR_MW) mask_s[wd * LR_BLOCK + threadIdx.x] = cmask;
+                }
+            }
+        }
+        if constexpr (FL) {
+            const int done = jt0 - jt, rem = done & 31;                        // jt0 < 0: nothing walked
+            if (jt0 >= 0 && rem != 0 && (done >> 5) < LR_MW) mask_s[(done >> 5) * LR_BLOCK + threadIdx.x] = cmask << (32 - rem);
         }
     };
     auto for_slice = [&](int R, bool needq, auto &&f) {
         Pref p = slice_prefetch(R, needq);
-        for_slice_from(p, needq, f);
+        for_slice_from(p, needq, f, std::false_type());
     };
     auto group_or = [&](bool v) -> bool {
         const unsigned long long b = __ballot(v ? 1 : 0);
@@ -230,6 +254,13 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     bool active = false, begin = false, converged = false, refused = false;
     uint32_t episode = 0;
     long long wmain = 0, wextra = 0;
+    // Spread candidates.  The weighted spread (frirl_update_sarsa.c:76-131) moves the rules whose weight w_r / sum(w) for the pending point
+    // (s, a) exceeds weight_significant.  sum(w) of this step's pending conclusion is known from BELOW before the sweep starts: it is the
+    // sum the previous sweep formed for the action it then chose (same point, same rules in the same order; a rule appended since only adds
+    // a non-negative term, and rounding is monotone).  `thr` = weight_significant (less a 4e-9 margin) x that sum: the sweep flags the rules
+    // with w_r > thr, one bit each, and the spread visits the flagged rules only -- the same arithmetic on a superset of the rules the full
+    // walk would move.  0 = unknown (first step after a launch boundary): the spread walks all rules.
+    double thr = 0.0;
 #pragma unroll
     for (int k = 0; k < NS; k++) states[k] = exists ? ev.states[(size_t)e * NS + k] : 0.0;
 #pragma unroll
@@ -318,7 +349,8 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                 const double wi = shepard_w(d, pk);
                 sv[NA] = __fma_rn(wi, cq, sv[NA]);
                 sw[NA] = sw[NA] + wi;
-            });
+                return (uint32_t)__double2hiint(thr - wi);                    // sign bit: w_r > thr
+            }, std::true_type());
             wmain += R;
         }
         if (H > 1) {                                                          // the H rule slices of every conclusion, a few conclusions at a time
@@ -359,8 +391,19 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                 const int a0 = e_greedy(ag, ci, (uint32_t)e, episode, 0u);                              // :78-82
                 q_ant[NS] = grid_s[NS * FRIRL_HIP_MAX_GRID + a0];
                 begin = false;
+                double w0 = sw[0];
+#pragma unroll
+                for (int a = 1; a < NA; a++) w0 = (a == a0) ? sw[a] : w0;
+                thr = (ag.weight_significant * (1.0 - 4e-9)) * w0;
             } else {
                 const int chosen = e_greedy(ag, ci, (uint32_t)e, episode, (uint32_t)steps + 1u);
+                const bool flags_known = thr > 0.0 && thr < __builtin_inf();                            // this step's flags were taken against a real bound
+                {
+                    double w0 = sw[0];
+#pragma unroll
+                    for (int a = 1; a < NA; a++) w0 = (a == chosen) ? sw[a] : w0;
+                    thr = (ag.weight_significant * (1.0 - 4e-9)) * w0;                                  // (s', a') is the next pending point
+                }
                 double qp = bv;                                                                          // Q(s',a'), frirl_update_sarsa.c:356
                 if (chosen != ci) {                                                                      // an exploratory action: its own conclusion
                     double v = sv[0], w = sw[0];
@@ -457,15 +500,32 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                                 if (ev.spread_R) ev.spread_R[e] = R;
                             }
                             const double iws = 1.0 / ws1;
-                            for_slice(R, false, [&](int r, const double (&c)[NANT], double) {           // K6 + K7, every lane its own rules
+                            auto move = [&](int r, const double (&c)[NANT]) {                           // K6 + K7 for one rule of this lane
                                 const double d0 = ve1[0] - c[0];
                                 double s = d0 * d0;
 #pragma unroll
                                 for (int k = 1; k < NANT; k++) { const double d = ve1[k] - c[k]; s = __fma_rn(d, d, s); }
                                 const double w = shepard_w(s, pk) * iws;
                                 if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; Tq_l[(size_t)(r / H) * 64] = qnow + t; }
-                            });
-                            wextra += R;
+                            };
+                            const int jt0 = (R - h + H - 1) / H - 1;                                    // the walk the flags were taken on
+                            if (group_or(!flags_known || jt0 >= LR_MW * 32)) {
+                                for_slice(R, false, [&](int r, const double (&c)[NANT], double) { move(r, c); });   // every lane its own rules
+                                wextra += R;
+                            } else {
+                                const int nw = (jt0 + 32) >> 5;
+                                for (int wd = 0; wd < nw; wd++) {
+                                    uint32_t m = mask_s[wd * LR_BLOCK + threadIdx.x];
+                                    while (m) {
+                                        const int b = __clz(m);
+                                        m &= ~(0x80000000u >> b);
+                                        const int j = jt0 - (wd * 32 + b);
+                                        double c[NANT];
+                                        decode(Ti_l[(long)j * 64], c);
+                                        move(j * H + h, c);
+                                    }
+                                }
+                            }
                         }
                     }
                     __threadfence_block();          // the group's stores are visible to its other lanes before the next sweep
