@@ -84,6 +84,22 @@ extern "C" size_t frirl_hip_learn_workspace_bytes(int32_t nant, int32_t E, int32
     return m * (16 + 8 + 8) + 256;
 }
 
+#ifdef LEARN_TIMING
+static unsigned long long *learn_timing_buffer()
+{
+    static unsigned long long *p = nullptr;
+    if (!p) { if (hipMalloc(&p, 16 * 8) != hipSuccess) return nullptr; (void)hipMemset(p, 0, 16 * 8); }
+    return p;
+}
+extern "C" int frirl_hip_learn_timing(unsigned long long *out16)       // read and reset (experimental builds, tools/exp)
+{
+    unsigned long long *p = learn_timing_buffer();
+    if (!p || hipMemcpy(out16, p, 16 * 8, hipMemcpyDeviceToHost) != hipSuccess) return FRIRL_HIP_EINVAL;
+    (void)hipMemset(p, 0, 16 * 8);
+    return FRIRL_HIP_OK;
+}
+#endif
+
 // One chunk of the construct loop for the agents in `live` (device array of nlive agent ids, or NULL = agents 0..nlive-1):
 // see include/frirl_hip.h.
 extern "C" int frirl_hip_learn_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
@@ -106,6 +122,9 @@ extern "C" int frirl_hip_learn_run(const frirl_hip_tables *t, const frirl_hip_ru
     la.live = live; la.nlive = nlive;
     la.rb = b->rb; la.uidx = b->uidx; la.nrules = b->nrules; la.maxR = b->maxR;
     la.work = work; la.steps_total = steps_total; la.budget = budget_steps; la.max_episodes = max_episodes;
+#ifdef LEARN_TIMING
+    la.timing = learn_timing_buffer();
+#endif
     const int H = learn_slices(nlive);
     if (t->nant == 3) frirl_learn_launch_mountaincar(H, t, b, agent, envs, conv, la, s);
     else if (agent->A == 3) { if (H <= 8) frirl_learn_launch_acrobot_lo(H, t, b, agent, envs, conv, la, s); else frirl_learn_launch_acrobot_hi(H, t, b, agent, envs, conv, la, s); }

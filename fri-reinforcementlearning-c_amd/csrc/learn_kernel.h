@@ -49,9 +49,18 @@ struct LearnArgs {
     int maxR;
     int64_t *work;               // [E][2] rule visits of the main sweeps / of the extra sweeps (snapped point, weighted spread), or NULL
     int64_t *steps_total;        // [E] environment steps so far, or NULL
-    int budget;                  // environment steps per agent in this launch
+    int budget;                  // environment steps in this launch for an agent with the launch's mean rule count (see work budget)
+    long long *sum_rules;        // sum of the live agents' rule counts at the start of the launch (import kernel)
     int max_episodes;            // the loop runs episodes 1 .. max_episodes - 1 (frirl_sequential_run.c:51,59)
+#ifdef LEARN_TIMING
+    unsigned long long *timing;  // [16] cycles per section of the step, summed over waves (tools/exp builds only)
+#endif
 };
+#ifdef LEARN_TIMING
+#define LT_MARK(i) do { const unsigned long long now_ = clock64(); if ((__ffsll((long long)__ballot(1)) - 1) == lane) { tim_s[wave][i] += now_ - tim_s[wave][15]; tim_s[wave][15] = now_; } } while (0)
+#else
+#define LT_MARK(i) do { } while (0)
+#endif
 
 template <int BITS>
 struct Packed {
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(256) void learn_import_kernel(const LearnArgs la, i
     const int e = exists ? (la.live ? la.live[slot] : slot) : 0;
     const int R = exists ? la.nrules[e] : 0;
     const int nj = (R + H - 1) / H;
+    if (threadIdx.x < 64 && h == 0 && exists) atomicAdd(reinterpret_cast<unsigned long long *>(la.sum_rules), (unsigned long long)R);
     int njw = nj;                                               // rounds needed by any agent of the tile
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(njw, off, FRIRL_WAVE); njw = o > njw ? o : njw; }
     for (int j = threadIdx.x / 64; j < njw; j += 4) {
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     __shared__ double tab_s[(LU ? 2 : 1) * NANT * TS];
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
     __shared__ double udiv[8];                                                // FIVEInit.c:244-248, once instead of per observation
+    __shared__ unsigned aidx_s[NA];                                           // universe index of every action value
     __shared__ double cold_s[LR_WPB * (FRIRL_WAVE / H) * NCOLD];
     __shared__ uint32_t mask_s[LR_MW * LR_BLOCK];                             // [word][thread]: spread candidates of the sweep (see `thr`)
     static_assert(32 % (2 * UR) == 0, "a flag word is filled by whole loop iterations");
@@ -153,7 +164,11 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     const int USTR = LU ? TS : U;                                             // row stride of `us`
     if ((int)threadIdx.x < NANT) udiv[threadIdx.x] = universe_div(us + (size_t)threadIdx.x * USTR, U);
     __syncthreads();
-    auto observe = [&](int k, double x) { const double *uni = us + (size_t)k * USTR; return ves[(size_t)k * TS + snap_index(uni, U, x, udiv[k])]; };
+    // VE value of x in dimension k and the universe index it snaps to (five_rule_distance.c:75,80)
+    auto locate = [&](int k, double x, unsigned &idx) { const double *uni = us + (size_t)k * USTR; idx = snap_index(uni, U, x, udiv[k]); return ves[(size_t)k * TS + idx]; };
+    if ((int)threadIdx.x < NA) aidx_s[threadIdx.x] = snap_index(us + (size_t)NS * USTR, U, grid_s[NS * FRIRL_HIP_MAX_GRID + threadIdx.x], udiv[NS]);
+    __syncthreads();
+    auto pack = [&](uint32_t (&w)[W], int k, unsigned idx) { w[k / FPW] |= (idx & ((1u << BITS) - 1u)) << (BITS * (k % FPW)); };
     const size_t tbase = ((size_t)(tile < la.tiles ? tile : 0) * (la.njmax + LR_PADROWS) + LR_PADROWS) * 64;
     const RecI *Ti_l = reinterpret_cast<const RecI *>(la.Ti) + tbase + lane;      // this lane's rules: element j at [j * 64]
     double *Tq_l = la.Tq + tbase + lane, *Tp_l = la.Tp + tbase + lane;
@@ -261,10 +276,28 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     // with w_r > thr, one bit each, and the spread visits the flagged rules only -- the same arithmetic on a superset of the rules the full
     // walk would move.  0 = unknown (first step after a launch boundary): the spread walks all rules.
     double thr = 0.0;
+    // Work budget.  All waves of a launch are resident together, so the launch lasts as long as its slowest wave; agents are sorted by rule
+    // count (a wave's agents walk as many rules as the largest rule base among them), so with the same number of steps for everyone the
+    // waves of the large rule bases would finish long after the others.  Each agent therefore stops after the WORK of `budget` steps of an
+    // agent with the launch's mean rule count -- rules walked by its fused sweeps plus a per-step constant (the environment's own dynamics,
+    // butterfly and update are worth ~24 rules per lane) -- but never after more than 4 x budget steps.  Where a launch cuts an agent's
+    // run does not change what it computes (tests/test_hip_learn.py).
+    constexpr long long STEP_RULES = 24 * H;
+    const long long work_budget = (long long)la.budget * (*la.sum_rules / (la.nlive > 0 ? la.nlive : 1) + STEP_RULES);
+    // The pending point (s, a) of a step is the (s', a') of the step before: its VE values, its packed universe indices and "every
+    // coordinate is a grid value" (true for everything env_quantize and the action grid produce: frirl_check_possible_states then returns
+    // its argument, so the snapped point of frirl_update_sarsa.c:366-370 is the point itself) are carried over instead of recomputed.
+    double ve1[NANT];
+    uint32_t pk1[W];
+    bool ongrid = false;                                                      // unknown after a launch boundary and for a start state
 #pragma unroll
     for (int k = 0; k < NS; k++) states[k] = exists ? ev.states[(size_t)e * NS + k] : 0.0;
 #pragma unroll
     for (int k = 0; k < NANT; k++) q_ant[k] = exists ? ev.q_ant[(size_t)e * NANT + k] : 0.0;
+#pragma unroll
+    for (int x = 0; x < W; x++) pk1[x] = 0u;
+#pragma unroll
+    for (int k = 0; k < NANT; k++) { unsigned i1; ve1[k] = locate(k, q_ant[k], i1); pack(pk1, k, i1); }
     if (exists) {
         R = la.nrules[e]; fus = ev.fus[e]; steps = ev.ep_steps[e]; total = ev.ep_reward[e];
         begin = ev.done[e] != 0;                                              // between two episodes: start the next one
@@ -274,9 +307,17 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
         active = !converged && nep < la.max_episodes - 1 && la.budget > 0;
     }
 
+#ifdef LEARN_TIMING
+    __shared__ unsigned long long tim_s[LR_WPB][16];
+    if (lane < 16) tim_s[wave][lane] = 0ull;
+    if (lane == 0) tim_s[wave][15] = clock64();
+#endif
     while (__any(active ? 1 : 0)) {
-        double cur[NS], cur_q[NANT], ve1[NANT], ve2[NS], reward = 0.0;
+        double cur[NS], cur_q[NANT], ve2[NS], reward = 0.0;
+        uint32_t pk2[W];
         int success = 0;
+#pragma unroll
+        for (int x = 0; x < W; x++) pk2[x] = 0u;
         Pref pmain = slice_prefetch(active ? R : 0, true);                    // in flight while the environment steps
         if (active) {
             if (begin) {                                                      // frirl_episode.c:46-48: q_states = states = start state
@@ -292,16 +333,13 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                 env_quantize(KIND, NS, grid_s, ag.grid_len, ag.grid_div, cur, cur_q);            // :112
             }
 #pragma unroll
-            for (int k = 0; k < NANT; k++) ve1[k] = observe(k, q_ant[k]);
-#pragma unroll
-            for (int k = 0; k < NS; k++) ve2[k] = observe(k, cur_q[k]);
+            for (int k = 0; k < NS; k++) { unsigned i2; ve2[k] = locate(k, cur_q[k], i2); pack(pk2, k, i2); }
         } else {
-#pragma unroll
-            for (int k = 0; k < NANT; k++) ve1[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < NS; k++) { ve2[k] = 0.0; cur[k] = 0.0; cur_q[k] = 0.0; }
         }
 
+        LT_MARK(0);
         // ---- the agent's cold state leaves the registers for the duration of the sweep: it is the same in all H lanes of the group,
         //      so lane 0 parks it in LDS and every lane reads it back afterwards (the compiler may not forward across the fences);
         //      without this the kernel needs > 256 VGPRs and spills to scratch inside the rule loop
@@ -316,6 +354,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             ci[0] = fus; ci[1] = steps; ci[2] = prevR; ci[3] = prev_steps; ci[4] = nep; ci[5] = lsteps; ci[6] = (int)episode; ci[7] = success;
         }
         asm volatile("" ::: "memory");
+        LT_MARK(1);
 
         // ---- one pass over this lane's rules: Q(s', a) for every action (frirl_get_best_action, :148) and Q(s, a) of the pending
         //      update (frirl_update_sarsa.c:357); an exact hit poisons the sums of its own conclusion, which are then not read
@@ -353,6 +392,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             }, std::true_type());
             wmain += R;
         }
+        LT_MARK(2);
         if (H > 1) {                                                          // the H rule slices of every conclusion, a few conclusions at a time
             constexpr int CH = 4;
 #pragma unroll
@@ -377,6 +417,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             const int *ci = reinterpret_cast<const int *>(cold + 2 * NS + 2 * NANT + 3);
             fus = ci[0]; steps = ci[1]; prevR = ci[2]; prev_steps = ci[3]; nep = ci[4]; lsteps = ci[5]; episode = (uint32_t)ci[6]; success = ci[7];
         }
+        LT_MARK(3);
         if (active) {
             // greedy action: first maximum in action order (max.inl:21)
             double bv = 0.0;
@@ -395,6 +436,19 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
 #pragma unroll
                 for (int a = 1; a < NA; a++) w0 = (a == a0) ? sw[a] : w0;
                 thr = (ag.weight_significant * (1.0 - 4e-9)) * w0;
+#pragma unroll
+                for (int k = 0; k < NS; k++) ve1[k] = ve2[k];                                           // (start state, a0) is the next pending point
+                ve1[NS] = ves[NS * TS + aidx_s[a0]];
+#pragma unroll
+                for (int x = 0; x < W; x++) pk1[x] = pk2[x];
+                pack(pk1, NS, aidx_s[a0]);
+                {                                                                                       // a start state may lie anywhere:
+                    double sq[NS];                                                                      // a grid value quantizes to itself
+                    env_quantize(KIND, NS, grid_s, ag.grid_len, ag.grid_div, q_ant, sq);
+                    ongrid = KIND != FRIRL_HIP_ENV_CARTPOLE;
+#pragma unroll
+                    for (int k = 0; k < NS; k++) ongrid = ongrid && (sq[k] == q_ant[k]);
+                }
             } else {
                 const int chosen = e_greedy(ag, ci, (uint32_t)e, episode, (uint32_t)steps + 1u);
                 const bool flags_known = thr > 0.0 && thr < __builtin_inf();                            // this step's flags were taken against a real bound
@@ -419,61 +473,65 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
 
                 // ---- frirl_update_sarsa + update_rules (frirl_update_sarsa.c:348-385, :22-143): every lane of the group follows the
                 //      same branch; single stores are issued by lane 0, the weighted spread by every lane for its own rules
+                LT_MARK(4);
                 if (!ag.evaluate) {                                                                     // frirl_episode.c:155
                     const double qdiff = ag.alpha * (reward + ag.gamma * qp - qnow);                    // :358
                     bool finished = false;
                     if (qdiff > ag.qdiff_pos_boundary || qdiff < ag.qdiff_neg_boundary) {               // :363
                         double rant[NANT], ve3[NANT];
-                        unsigned idx3[NANT];
-                        bool same = true;
+                        uint32_t pk3[W];
 #pragma unroll
-                        for (int k = 0; k < NANT; k++) {
-                            rant[k] = check_possible_states(q_ant[k], grid_s + k * FRIRL_HIP_MAX_GRID, ag.grid_len[k]);   // :146-170
-                            const double *uni = us + (size_t)k * USTR;
-                            idx3[k] = snap_index(uni, U, rant[k], udiv[k]);
-                            ve3[k] = ves[(size_t)k * TS + idx3[k]];
-                            same = same && (ve3[k] == ve1[k]);
-                        }
+                        for (int k = 0; k < NANT; k++) { rant[k] = q_ant[k]; ve3[k] = ve1[k]; }
+#pragma unroll
+                        for (int x = 0; x < W; x++) pk3[x] = pk1[x];
                         double v3 = vs1, w3 = ws1;                                                      // :370 (same VE point => same sums)
                         unsigned hit3 = hit1;
-                        if (!same) {
-                            v3 = 0.0; w3 = 0.0; hit3 = FRIRL_HIP_NO_HIT;
-                            for_slice(R, true, [&](int r, const double (&c)[NANT], double cq) {
-                                const double d0 = ve3[0] - c[0];
-                                double s = d0 * d0;
+                        if (!ongrid) {                                                                  // :146-170, else the point is its own snap
+                            bool same = true;
 #pragma unroll
-                                for (int k = 1; k < NANT; k++) { const double d = ve3[k] - c[k]; s = __fma_rn(d, d, s); }
-                                hit3 = (s == 0.0) ? (unsigned)r : hit3;
-                                const double wi = shepard_w(s, pk);
-                                v3 = __fma_rn(wi, cq, v3);
-                                w3 = w3 + wi;
-                            });
-                            for (int off = 1; off < H; off <<= 1) {
-                                const double tv = __shfl_xor(v3, off, FRIRL_WAVE), tw = __shfl_xor(w3, off, FRIRL_WAVE);
-                                const unsigned th = (unsigned)__shfl_xor((int)hit3, off, FRIRL_WAVE);
-                                v3 = v3 + tv; w3 = w3 + tw; hit3 = th < hit3 ? th : hit3;
+                            for (int x = 0; x < W; x++) pk3[x] = 0u;
+#pragma unroll
+                            for (int k = 0; k < NANT; k++) {
+                                rant[k] = check_possible_states(q_ant[k], grid_s + k * FRIRL_HIP_MAX_GRID, ag.grid_len[k]);
+                                unsigned i3;
+                                ve3[k] = locate(k, rant[k], i3);
+                                pack(pk3, k, i3);
+                                same = same && (ve3[k] == ve1[k]);
                             }
-                            wextra += R;
+                            if (!same) {
+                                v3 = 0.0; w3 = 0.0; hit3 = FRIRL_HIP_NO_HIT;
+                                for_slice(R, true, [&](int r, const double (&c)[NANT], double cq) {
+                                    const double d0 = ve3[0] - c[0];
+                                    double s = d0 * d0;
+#pragma unroll
+                                    for (int k = 1; k < NANT; k++) { const double d = ve3[k] - c[k]; s = __fma_rn(d, d, s); }
+                                    hit3 = (s == 0.0) ? (unsigned)r : hit3;
+                                    const double wi = shepard_w(s, pk);
+                                    v3 = __fma_rn(wi, cq, v3);
+                                    w3 = w3 + wi;
+                                });
+                                for (int off = 1; off < H; off <<= 1) {
+                                    const double tv = __shfl_xor(v3, off, FRIRL_WAVE), tw = __shfl_xor(w3, off, FRIRL_WAVE);
+                                    const unsigned th = (unsigned)__shfl_xor((int)hit3, off, FRIRL_WAVE);
+                                    v3 = v3 + tv; w3 = w3 + tw; hit3 = th < hit3 ? th : hit3;
+                                }
+                                wextra += R;
+                            }
                         }
                         if (hit3 == FRIRL_HIP_NO_HIT) {                                                 // :373-377 append and leave
                             if (R >= maxR) {
                                 refused = true;
                             } else {
                                 if (h == 0) {
-                                    uint32_t w[W];
-#pragma unroll
-                                    for (int x = 0; x < W; x++) w[x] = 0u;
-#pragma unroll
-                                    for (int k = 0; k < NANT; k++) w[k / FPW] |= (idx3[k] & ((1u << BITS) - 1u)) << (BITS * (k % FPW));
                                     RecI x;
-                                    if constexpr (W == 1) { x = w[0]; } else if constexpr (W == 2) { x.x = w[0]; x.y = w[1]; } else { x.x = w[0]; x.y = w[1]; x.z = w[2]; x.w = W > 3 ? w[W - 1] : 0u; }
+                                    if constexpr (W == 1) { x = pk3[0]; } else if constexpr (W == 2) { x.x = pk3[0]; x.y = pk3[1]; } else { x.x = pk3[0]; x.y = pk3[1]; x.z = pk3[2]; x.w = W > 3 ? pk3[W - 1] : 0u; }
                                     const size_t o = (size_t)(R / H) * 64 + (R % H);
                                     Ti_g[o] = x;
                                     Tq_g[o] = v3 / w3 + qdiff;
 #pragma unroll
                                     for (int k = 0; k < NANT; k++) {
                                         la.rb[((size_t)e * (NANT + 1) + k) * maxR + R] = ve3[k];        // five_add_rule.c:80-81 (canonical slab)
-                                        la.uidx[((size_t)e * NANT + k) * maxR + R] = (uint16_t)idx3[k];  // :76
+                                        la.uidx[((size_t)e * NANT + k) * maxR + R] = (uint16_t)((pk3[k / FPW] >> (BITS * (k % FPW))) & ((1u << BITS) - 1u));  // :76
                                         if (ev.rant) ev.rant[((size_t)e * NANT + k) * maxR + R] = rant[k];
                                     }
                                 }
@@ -485,6 +543,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                             fus = 0;                                                                    // :378
                         }
                     }
+                    LT_MARK(5);
                     if (!finished) {
                         const int rules = fus ? R - 1 : R;                                              // :30-33
                         if (hit1 != FRIRL_HIP_NO_HIT && (ag.skip_rules == 0 || (ag.skip_rules == 1 && (int)hit1 < rules))) {
@@ -513,6 +572,11 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                                 for_slice(R, false, [&](int r, const double (&c)[NANT], double) { move(r, c); });   // every lane its own rules
                                 wextra += R;
                             } else {
+                                // this lane's flagged rules (rarely more than two or three); their records are then loaded together
+                                constexpr int NCD = 8;
+                                int js[NCD], nc = 0;
+#pragma unroll
+                                for (int i = 0; i < NCD; i++) js[i] = 0;
                                 const int nw = (jt0 + 32) >> 5;
                                 for (int wd = 0; wd < nw; wd++) {
                                     uint32_t m = mask_s[wd * LR_BLOCK + threadIdx.x];
@@ -520,19 +584,35 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                                         const int b = __clz(m);
                                         m &= ~(0x80000000u >> b);
                                         const int j = jt0 - (wd * 32 + b);
-                                        double c[NANT];
-                                        decode(Ti_l[(long)j * 64], c);
-                                        move(j * H + h, c);
+#pragma unroll
+                                        for (int i = 0; i < NCD; i++) js[i] = (nc == i) ? j : js[i];
+                                        nc++;
                                     }
+                                }
+                                if (group_or(nc > NCD)) {
+                                    for_slice(R, false, [&](int r, const double (&c)[NANT], double) { move(r, c); });
+                                    wextra += R;
+                                } else {
+                                    RecI xs[NCD];
+#pragma unroll
+                                    for (int i = 0; i < NCD; i++) xs[i] = Ti_l[(long)js[i] * 64];
+#pragma unroll
+                                    for (int i = 0; i < NCD; i++) if (i < nc) { double c[NANT]; decode(xs[i], c); move(js[i] * H + h, c); }
                                 }
                             }
                         }
                     }
                     __threadfence_block();          // the group's stores are visible to its other lanes before the next sweep
+                    LT_MARK(6);
                 }
 #pragma unroll
-                for (int k = 0; k < NS; k++) { states[k] = cur[k]; q_ant[k] = cur_q[k]; }               // :163-168
+                for (int k = 0; k < NS; k++) { states[k] = cur[k]; q_ant[k] = cur_q[k]; ve1[k] = ve2[k]; }   // :163-168
                 q_ant[NS] = cur_q[NS];
+                ve1[NS] = ves[NS * TS + aidx_s[chosen]];
+#pragma unroll
+                for (int x = 0; x < W; x++) pk1[x] = pk2[x];
+                pack(pk1, NS, aidx_s[chosen]);
+                ongrid = KIND != FRIRL_HIP_ENV_CARTPOLE;                                               // env_quantize's grid values (envs.h)
                 steps++;                                                                                // :174
                 lsteps++;
                 total = total + reward;                                                                 // :107
@@ -542,10 +622,20 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                     const bool same = prevR == R && prev_steps == steps && total > ag.reward_good_above && prev_reward == total;
                     bool moved = false;
                     const int nj = (R - h + H - 1) / H;
-                    for (int j = 0; j < nj; j++) {
-                        const double q = Tq_l[(size_t)j * 64];
-                        if (same && fabs(q - Tp_l[(size_t)j * 64]) >= ag.qdiff_final_tolerance) moved = true;
-                        Tp_l[(size_t)j * 64] = q;
+                    constexpr int EB = 16;                                    // loads of a batch in flight together
+                    for (int j0 = 0; j0 < nj; j0 += EB) {
+                        double qn[EB];
+#pragma unroll
+                        for (int t = 0; t < EB; t++) qn[t] = Tq_l[(size_t)(j0 + t < nj ? j0 + t : 0) * 64];
+                        if (same) {
+                            double qp[EB];
+#pragma unroll
+                            for (int t = 0; t < EB; t++) qp[t] = Tp_l[(size_t)(j0 + t < nj ? j0 + t : 0) * 64];
+#pragma unroll
+                            for (int t = 0; t < EB; t++) if (j0 + t < nj && fabs(qn[t] - qp[t]) >= ag.qdiff_final_tolerance) moved = true;
+                        }
+#pragma unroll
+                        for (int t = 0; t < EB; t++) if (j0 + t < nj) Tp_l[(size_t)(j0 + t) * 64] = qn[t];
                     }
                     moved = group_or(moved);
                     nep++;
@@ -554,10 +644,15 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                     begin = true;
                     if (converged || nep >= la.max_episodes - 1) active = false;
                 }
-                if (lsteps >= la.budget) active = false;
+                LT_MARK(7);
+                if (wmain + (long long)lsteps * STEP_RULES >= work_budget || lsteps >= 4 * la.budget) active = false;
             }
         }
+        LT_MARK(8);
     }
+#ifdef LEARN_TIMING
+    if (lane < 15 && la.timing) atomicAdd(&la.timing[lane], tim_s[wave][lane]);
+#endif
 
     if (!exists || h != 0) return;
 #pragma unroll
@@ -591,6 +686,8 @@ inline void launch_learn(const frirl_hip_tables *t, const frirl_hip_rulebases *b
     char *ws = reinterpret_cast<char *>(la.Ti);
     la.Tq = reinterpret_cast<double *>(ws + ((n * W * sizeof(uint32_t) + 15) / 16) * 16);
     la.Tp = la.Tq + n;
+    la.sum_rules = reinterpret_cast<long long *>(la.Tp + n);                  // inside the 256 B the workspace size adds at its end
+    (void)hipMemsetAsync(la.sum_rules, 0, sizeof(long long), s);
     const size_t dyn = 0;
     hipLaunchKernelGGL((frirl::learn_import_kernel<N, BITS>), dim3(la.tiles), dim3(256), 0, s, la, H, cv->prev_rconc);
     const int blocks = (la.tiles + frirl::LR_WPB - 1) / frirl::LR_WPB;

@@ -332,7 +332,10 @@ int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_ruleb
  * rule bases, persistent: every agent of `live` ([dev] nlive agent ids, NULL = agents 0..nlive-1) runs episode after episode at its
  * own pace -- frirl_episode's loop, the SARSA update and, at each episode's end, the loop's bookkeeping (same rule count, steps and
  * good reward as the previous episode and no consequent moved by qdiff_final_tolerance => "RB considered complete", :83-148; then the
- * snapshot, :68-72) -- until it has converged, has made budget_steps steps in this call, or has run max_episodes - 1 episodes
+ * snapshot, :68-72) -- until it has converged, has used its budget for this call, or has run max_episodes - 1 episodes; the budget is
+ * the WORK of budget_steps steps of an agent with the call's mean rule count (agents with larger rule bases make fewer steps, with
+ * smaller ones more, at most 4 x budget_steps: all waves of the launch then finish together; where a call cuts an agent's run does not
+ * change what the agent computes)
  * (:51,59).  Nothing in a launch waits for the longest episode of the batch: the reference's many-agent modes diversify the start
  * states (frirl_agent.c:121-139), so agents are never in step.  Between calls the host compacts the agents that are still learning
  * into `live`; the fewer they are, the more lanes each gets (2 ... 64 rule slices per agent: the largest power of two that keeps all of them resident).
@@ -340,7 +343,9 @@ int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_ruleb
  * on return done[e] = 1 iff the agent stopped at an episode boundary, ep_steps / ep_reward = the running or last episode,
  * conv->episodes / converged / prev_* as frirl_hip_convergence_update leaves them, status[e] = FRIRL_HIP_UPD_FULL iff an append was
  * refused.  work ([dev][E][2] int64, or NULL) accumulates the rule visits of the fused sweeps (one visit = one rule evaluated for
- * all A + 1 conclusions of a step) and of the extra single-conclusion sweeps (snapped point, weighted spread); steps_total
+ * all A + 1 conclusions of a step) and of the extra single-conclusion sweeps (the snapped point; a weighted spread that has to
+ * walk the whole rule base -- normally it visits only the handful of rules the fused sweep flagged as possibly significant, which
+ * are not counted); steps_total
  * ([dev][E] int64, or NULL) the environment steps.  Needs the 16-bit index mirror.  Covered shapes: frirl_hip_learn_supported
  * (mountaincar and acrobot: 3 actions, universes of <= 64 points; cartpole's 21 actions stay with frirl_hip_episode_run_lanes).
  * Decisions follow the oracle exactly on the demos (tests/test_hip_learn.py); interpolated Q within the 1e-6 contract (per-lane sums in
