@@ -419,7 +419,7 @@ def learning_and_evaluation(B, w, world, rank):
                 chunks.append((LEARN_AGENTS if live is None else int(live.numel()), st))
             B.sync_all()
             t0 = time.perf_counter()
-            run = frirl_amd.train_persistent(lprob, lagent, lenvs, max_episodes=max_episodes, budget=1024, on_chunk=on_chunk)
+            run = frirl_amd.train_persistent(lprob, lagent, lenvs, max_episodes=max_episodes, budget=512, on_chunk=on_chunk)
             B.sync_all()
             ldt = D.max_over_ranks(time.perf_counter() - t0, device)
             wk = run.work.sum(0).double()

@@ -80,6 +80,7 @@ class ConvergenceDesc(C.Structure):
 
 _lib = None
 _DP = C.POINTER(C.c_double)
+LEARN_CHUNK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32)      # frirl_hip_learn_chunk_fn
 
 # name -> (restype, argtypes); every symbol include/frirl_hip.h declares
 SIGNATURES = {
@@ -112,6 +113,10 @@ SIGNATURES = {
     "frirl_hip_learn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frirl_hip_learn_run": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
                                       C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "frirl_hip_learn_train_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "frirl_hip_learn_train": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.POINTER(ConvergenceDesc),
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32),
+                                        LEARN_CHUNK_FN, C.c_void_p, C.c_void_p]),
     "five_hip_add_rule": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "frirl_hip_update_sarsa": (C.c_int, [C.POINTER(Tables), C.POINTER(RuleBases), C.POINTER(AgentDesc), C.POINTER(EnvsDesc), C.c_void_p,
@@ -597,50 +602,45 @@ class LearnRun:
 
 
 def train_persistent(problem, agent, envs, max_episodes=1000, budget=4096, on_chunk=None, stream=None):
-    """The construct loop of frirl_sequential_run for E agents through frirl_hip_learn_run: every agent runs its episodes
-    back to back on the device; after each launch (<= `budget` steps per agent) the agents that are still learning are
-    compacted and launched again until none is left.  on_chunk(launch index, live agent ids, conv) is called after every
-    launch (the place for the per-chunk reward statistics all-reduce).  Returns a LearnRun."""
+    """The construct loop of frirl_sequential_run for E agents through frirl_hip_learn_train: every agent runs its episodes
+    back to back on the device; after each launch (the work of `budget` steps of a mean agent) the agents that are still
+    learning are compacted and launched again until none is left -- the launch plan, the queue and the compaction are the
+    library's (csrc/learn.hip), the host reads two counters per launch.  on_chunk(launch index, live agent ids, conv) is
+    called after every launch (the place for the per-chunk reward statistics).  Returns a LearnRun."""
     import torch
     dev_ = problem.rb.device
     conv = Convergence(problem, dev_)
     envs.done.fill_(1)                                   # fresh agents: every one starts its first episode
     steps_total = torch.zeros((problem.E,), dtype=torch.int64, device=dev_)
     work = torch.zeros((problem.E, 2), dtype=torch.int64, device=dev_)
-    need = lib().frirl_hip_learn_workspace_bytes(problem.nant, problem.E, problem.maxR, agent.A)
+    need = lib().frirl_hip_learn_train_workspace_bytes(problem.nant, problem.E, problem.maxR, agent.A)
     ws = getattr(problem, "_learn_ws", None)
     if ws is None or ws.numel() * 8 < need:
         ws = torch.empty(((need + 7) // 8,), dtype=torch.float64, device=dev_)
         problem._learn_ws = ws
-    problem._learn_progress = (steps_total, work)                         # for on_chunk callbacks that report per-launch progress
-    order = torch.arange(problem.E, dtype=torch.int32, device=dev_)      # the agents that are still learning, next in line first
-    launches = 0
-    mean_rules = 0
-    while order.numel() > 0:
-        H, take = C.c_int32(), C.c_int32()
-        check(lib().frirl_hip_learn_plan(int(order.numel()), mean_rules, C.byref(H), C.byref(take)), "frirl_hip_learn_plan")
-        n = take.value
-        # agents of one wave walk as many rules as the largest rule base among them: neighbours in the launch get similar rule counts
-        live = order[:n]
-        live = live[torch.argsort(problem.nrules[live.long()], stable=True)].contiguous()
-        check(lib().frirl_hip_learn_run(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), C.byref(conv.desc),
-                                        _ptr(live), n, budget, max_episodes, _ptr(work), _ptr(steps_total),
-                                        _ptr(ws), ws.numel() * 8, _stream(stream)), "frirl_hip_learn_run")
-        launches += 1
-        conv.full |= (envs.status == UPD_FULL)
-        if on_chunk is not None:
-            on_chunk(launches, live, conv)
-        lv = live.long()
-        still = (conv.converged[lv] == 0) & (conv.episodes[lv] < max_episodes - 1)
-        # one host round trip per launch (the number of agents left); the agents that had to wait go first next time
-        order = torch.cat([order[n:], live[still]])
-        if order.numel() > 0:
-            mean_rules = int(problem.nrules[order.long()].float().mean().item())
+    problem._learn_progress = (steps_total, work)        # for on_chunk callbacks that report per-launch progress
+    ws32 = ws.view(torch.int32)
+    failure = []
+
+    def chunk(_user, launch, live_ptr, n):               # `live` is a slice of the workspace
+        try:
+            off = (live_ptr - ws.data_ptr()) // 4
+            on_chunk(launch, ws32[off:off + n], conv)
+        except BaseException as exc:                     # an exception must not unwind through the C frame
+            failure.append(exc)
+    cb = LEARN_CHUNK_FN(chunk) if on_chunk is not None else C.cast(None, LEARN_CHUNK_FN)
+    launches = C.c_int32(0)
+    refused = conv.full.view(torch.uint8)
+    check(lib().frirl_hip_learn_train(C.byref(problem.tables), C.byref(problem.bases), C.byref(agent.desc), C.byref(envs.desc), C.byref(conv.desc),
+                                      budget, max_episodes, _ptr(work), _ptr(steps_total), _ptr(refused), _ptr(ws), ws.numel() * 8,
+                                      C.byref(launches), cb, None, _stream(stream)), "frirl_hip_learn_train")
+    if failure:
+        raise failure[0]
     if conv.full_envs:
         import warnings
         warnings.warn(f"frirl_amd.train_persistent: {conv.full_envs} of {problem.E} rule bases reached their capacity of {problem.maxR} rules: "
                       "appends were refused (FRIRL_HIP_UPD_FULL) and those TD updates dropped", RuntimeWarning)
-    return LearnRun(conv, steps_total, work, launches)
+    return LearnRun(conv, steps_total, work, launches.value)
 
 
 def demo_describe(env):

@@ -131,3 +131,135 @@ extern "C" int frirl_hip_learn_run(const frirl_hip_tables *t, const frirl_hip_ru
     else { set_error("frirl_hip_learn_run: cartpole's 21 actions are not covered"); return FRIRL_HIP_EINVAL; }
     return check_launch("frirl_hip_learn_run");
 }
+
+
+// ---- the whole construct loop for E agents: launch plan, the agents' queue, and the compaction between launches -------------------
+// (host side of the reference's loop, frirl_sequential_run.c:55-165 run for every agent: nothing here touches a rule)
+namespace {
+constexpr int LQ_BLOCK = 1024, LQ_BINS = 4096;
+
+__global__ void learn_queue_init_kernel(int32_t *q, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = i;
+}
+
+// live[0 .. take) = the first `take` agents of the queue, ordered by rule count (counting sort in LDS; agents with the same count in
+// any order): agents of one wave walk as many rules as the largest rule base among them, so neighbours should have similar counts
+__global__ __launch_bounds__(LQ_BLOCK) void learn_queue_sort_kernel(const int32_t *__restrict__ q, int take, const int32_t *__restrict__ nrules, int shift,
+                                                                    int32_t *__restrict__ live)
+{
+    __shared__ int bins[LQ_BINS];
+    __shared__ int part[LQ_BLOCK];
+    for (int i = threadIdx.x; i < LQ_BINS; i += LQ_BLOCK) bins[i] = 0;
+    __syncthreads();
+    auto key = [&](int e) { const int k = nrules[e] >> shift; return k < 0 ? 0 : (k >= LQ_BINS ? LQ_BINS - 1 : k); };
+    for (int i = threadIdx.x; i < take; i += LQ_BLOCK) atomicAdd(&bins[key(q[i])], 1);
+    __syncthreads();
+    constexpr int PER = LQ_BINS / LQ_BLOCK;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int x = 0; x < PER; x++) { loc[x] = sum; sum += bins[threadIdx.x * PER + x]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < LQ_BLOCK; off <<= 1) {                 // inclusive scan of the per-thread sums
+        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const int base = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int x = 0; x < PER; x++) bins[threadIdx.x * PER + x] = base + loc[x];
+    __syncthreads();
+    for (int i = threadIdx.x; i < take; i += LQ_BLOCK) { const int e = q[i]; live[atomicAdd(&bins[key(e)], 1)] = e; }
+}
+
+// next queue = the agents that had to wait (q[take .. n)), then the agents of this launch that are still learning, in launch order;
+// counters[0] = its length, counters[1] = the sum of its agents' rule counts; refused[e] |= "an append was refused" (status)
+__global__ __launch_bounds__(LQ_BLOCK) void learn_queue_next_kernel(const int32_t *__restrict__ q, int n, int take, const int32_t *__restrict__ live,
+                                                                    const int32_t *__restrict__ converged, const int32_t *__restrict__ episodes, int max_episodes,
+                                                                    const int32_t *__restrict__ nrules, const int32_t *__restrict__ status, uint8_t *refused,
+                                                                    int32_t *__restrict__ nq, long long *counters)
+{
+    __shared__ int wsum[LQ_BLOCK / 64];
+    __shared__ int base_s;
+    __shared__ unsigned long long rsum_s;
+    if (threadIdx.x == 0) { base_s = n - take; rsum_s = 0ull; }
+    unsigned long long rsum = 0ull;
+    for (int i = threadIdx.x; i < n - take; i += LQ_BLOCK) { const int e = q[take + i]; nq[i] = e; rsum += (unsigned long long)nrules[e]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < take; i0 += LQ_BLOCK) {
+        const int i = i0 + threadIdx.x;
+        int e = 0;
+        bool keep = false;
+        if (i < take) {
+            e = live[i];
+            keep = converged[e] == 0 && episodes[e] < max_episodes - 1;
+            if (refused && status && status[e] == FRIRL_HIP_UPD_FULL) refused[e] = 1;
+        }
+        const unsigned long long b = __ballot(keep ? 1 : 0);
+        if (lane == 0) wsum[wave] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < LQ_BLOCK / 64; w++) { const int c = wsum[w]; if (w < wave) before += c; total += c; }
+        if (keep) { nq[base_s + before + __popcll(b & ((1ull << lane) - 1ull))] = e; rsum += (unsigned long long)nrules[e]; }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += total;
+        __syncthreads();
+    }
+    atomicAdd(&rsum_s, rsum);
+    __syncthreads();
+    if (threadIdx.x == 0) { counters[0] = base_s; counters[1] = (long long)rsum_s; }
+}
+
+size_t learn_train_tail_bytes(int E) { return ((size_t)3 * E * sizeof(int32_t) + 15) / 16 * 16 + 64; }
+}  // namespace
+
+extern "C" size_t frirl_hip_learn_train_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A)
+{
+    const size_t a = frirl_hip_learn_workspace_bytes(nant, E, maxR, A);
+    return a ? (a + 15) / 16 * 16 + learn_train_tail_bytes(E) : 0;
+}
+
+extern "C" int frirl_hip_learn_train(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
+                                     const frirl_hip_convergence *conv, int32_t budget_steps, int32_t max_episodes, int64_t *work, int64_t *steps_total,
+                                     uint8_t *refused, void *workspace, size_t workspace_bytes, int32_t *launches_out,
+                                     frirl_hip_learn_chunk_fn on_chunk, void *user, void *stream)
+{
+    int rc = frirl_check_episode(t, b, agent, envs, "frirl_hip_learn_train");
+    if (rc) return rc;
+    if (!conv || !conv->converged || !conv->episodes) { set_error("frirl_hip_learn_train: NULL convergence state"); return FRIRL_HIP_EINVAL; }
+    const int E = b->E;
+    const size_t run_bytes = (frirl_hip_learn_workspace_bytes(t->nant, E, b->maxR, agent->A) + 15) / 16 * 16;
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < run_bytes + learn_train_tail_bytes(E)) {
+        set_error("frirl_hip_learn_train: workspace %zu B < %zu B (frirl_hip_learn_train_workspace_bytes) or not 16-byte aligned", workspace_bytes, run_bytes + learn_train_tail_bytes(E));
+        return FRIRL_HIP_EINVAL;
+    }
+    hipStream_t s = as_stream(stream);
+    char *tail = static_cast<char *>(workspace) + run_bytes;
+    int32_t *qa = reinterpret_cast<int32_t *>(tail), *qb = qa + E, *live = qb + E;
+    long long *counters = reinterpret_cast<long long *>(tail + ((size_t)3 * E * sizeof(int32_t) + 15) / 16 * 16);
+    int shift = 0;
+    while ((b->maxR >> shift) >= LQ_BINS) shift++;
+    hipLaunchKernelGGL(learn_queue_init_kernel, dim3((E + 255) / 256 < 1024 ? (E + 255) / 256 : 1024), dim3(256), 0, s, qa, E);
+    int n = E, launches = 0;
+    long long mean_rules = 0;
+    while (n > 0) {
+        int32_t H = 0, take = 0;
+        if ((rc = frirl_hip_learn_plan(n, (int32_t)mean_rules, &H, &take)) != 0) return rc;
+        hipLaunchKernelGGL(learn_queue_sort_kernel, dim3(1), dim3(LQ_BLOCK), 0, s, qa, take, b->nrules, shift, live);
+        if ((rc = frirl_hip_learn_run(t, b, agent, envs, conv, live, take, budget_steps, max_episodes, work, steps_total, workspace, run_bytes, stream)) != 0) return rc;
+        launches++;
+        hipLaunchKernelGGL(learn_queue_next_kernel, dim3(1), dim3(LQ_BLOCK), 0, s, qa, n, take, live, conv->converged, conv->episodes, max_episodes, b->nrules,
+                           envs->status, refused, qb, counters);
+        long long h[2] = {0, 0};
+        if (hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return check_launch("frirl_hip_learn_train");
+        if (on_chunk) on_chunk(user, launches, live, take);
+        int32_t *x = qa; qa = qb; qb = x;
+        n = (int)h[0];
+        mean_rules = n > 0 ? h[1] / n : 0;
+    }
+    if (launches_out) *launches_out = launches;
+    return check_launch("frirl_hip_learn_train");
+}

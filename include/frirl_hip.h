@@ -360,6 +360,18 @@ size_t frirl_hip_learn_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, in
 int frirl_hip_learn_run(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
                         const frirl_hip_convergence *conv, const int32_t *live, int32_t nlive, int32_t budget_steps, int32_t max_episodes,
                         int64_t *work, int64_t *steps_total, void *workspace, size_t workspace_bytes, void *stream);
+/* The whole many-agent construct loop (every agent of the batch runs frirl_sequential_run's loop, :55-165, to its end): launch plan,
+ * the queue of agents that are still learning (those that had to wait go first), each launch's agents ordered by rule count, and the
+ * compaction between launches, all on the device; the host reads one pair of counters per launch.  envs->done[e] != 0 for a fresh agent
+ * (see frirl_hip_learn_run).  refused ([dev][E] bytes or NULL): set to 1 for agents whose rule base refused an append.  on_chunk (or
+ * NULL) is called after every launch, the stream idle, with the launch's agents ([dev] ids): the place for a per-chunk report.
+ * workspace: [dev] >= frirl_hip_learn_train_workspace_bytes, 16-byte aligned.  *launches_out = number of launches made. */
+typedef void (*frirl_hip_learn_chunk_fn)(void *user, int32_t launch, const int32_t *live, int32_t nlive);
+size_t frirl_hip_learn_train_workspace_bytes(int32_t nant, int32_t E, int32_t maxR, int32_t A);
+int frirl_hip_learn_train(const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *agent, const frirl_hip_envs *envs,
+                          const frirl_hip_convergence *conv, int32_t budget_steps, int32_t max_episodes, int64_t *work, int64_t *steps_total,
+                          uint8_t *refused, void *workspace, size_t workspace_bytes, int32_t *launches_out,
+                          frirl_hip_learn_chunk_fn on_chunk, void *user, void *stream);
 
 /* Persistent form for SMALL rule bases (the demos' learning regime): one wave keeps its environment's rule base,
  * the tables and the episode state in LDS and runs up to nsteps consecutive steps without a global round trip per
