@@ -78,3 +78,37 @@ def test_persistent_training_with_diversified_start_states(env, max_episodes):
         assert fr.total_steps == total[e], (e, fr.total_steps, total[e])
         check_agent_against_oracle(fr, prob, envs, e)
     assert ((converged == 1) | (episodes == max_episodes - 1)).all()
+
+
+@pytest.mark.parametrize("env,max_episodes,off_grid", [("mountaincar", 14, False), ("acrobot", 8, True)])
+def test_training_loop_on_the_device_with_thousands_of_agents(env, max_episodes, off_grid):
+    """3 000 diversified agents through frirl_hip_learn_train (csrc/learn.hip): the queue of live agents, the counting sort by rule
+    count and the compaction between launches run on the device, every launch under a work budget.  Sampled agents end exactly where
+    the oracle's runs from the same start states end -- also for start states OFF the state grid (the first update of an episode then
+    takes the possible-state search, :146-170; later ones use the carried grid point)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    E = 3000
+    d = frirl_amd.demo_describe(env)
+    rng = np.random.default_rng(5)
+    start = np.stack([rng.choice(d["grids"][k], E) for k in range(d["nstates"])], 1)
+    if off_grid:
+        step = np.array([d["grids"][k][1] - d["grids"][k][0] for k in range(d["nstates"])])
+        start = start + rng.uniform(-0.3, 0.3, start.shape) * step
+    prob, agent, envs = frirl_amd.demo_fresh_batch(env, E, 512, dev, start_states=torch.from_numpy(np.ascontiguousarray(start)).to(dev))
+    seen = []
+    run = frirl_amd.train_persistent(prob, agent, envs, max_episodes=max_episodes, budget=400, on_chunk=lambda i, live, conv: seen.append(int(live.numel())))
+    torch.cuda.synchronize()
+    assert seen[0] == E and run.launches == len(seen) and sorted(seen, reverse=True) == seen
+    conv = run.conv
+    episodes, converged, total = conv.episodes.cpu().numpy(), conv.converged.cpu().numpy(), run.steps_total.cpu().numpy()
+    assert ((converged == 1) | (episodes == max_episodes - 1)).all()
+    nr = prob.nrules.cpu().numpy()
+    sample = sorted({0, E - 1, int(np.argmax(nr)), int(np.argmin(nr)), 1234, 2047, 2048})      # small and large rule bases
+    for e in sample:
+        fr = ob.Frirl(env, trig_mode=1, maxR=512)
+        fr.set_start_state(start[e])
+        ok = fr.run(max_episodes=max_episodes)
+        assert ok == int(converged[e]), (e, ok, converged[e])
+        assert fr.total_steps == total[e], (e, fr.total_steps, total[e])
+        check_agent_against_oracle(fr, prob, envs, e)
