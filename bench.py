@@ -14,8 +14,9 @@ BASELINE.json's metric "rule-distance evals/sec (rules x envs)".  Default worklo
 (BASELINE.json configs[3] per GPU): acrobot tables (nant 5, U 41), 65 536 rules x 8 192 environments.  The second half
 of the metric, env-steps/sec, is the "env_steps" leg (fused do_action + reward + quantise + greedy sweep + SARSA update
 per environment); "learning" / "learning_diversified" = 65 536 agents per GPU learn the demo from the reference's initial
-rule base until every rule base is complete (replicas of the demo / one start state per agent; the job's report all-reduced
-per launch), with a COUNTED FP64-issue roofline (rule visits accumulated by the kernel); "evaluation" = greedy roll-outs of
+rule base until every rule base is complete (replicas of the demo / one start state per agent; "learning_diversified_4x" =
+the same with 262 144 agents per GPU, four times what the chip keeps resident: launches stay full until the end of the run;
+the job's report crosses the GPUs once per leg), with a COUNTED FP64-issue roofline (rule visits accumulated by the kernel); "evaluation" = greedy roll-outs of
 65 536 environments on one shared rule base, counted the same way; "other_configs" = the first two legs on BASELINE's other
 configurations (cfg2, cfg3, cfg5; N = 1 only); "cpu_baseline" = the genuine reference on the host cores (rank 0, N = 1,
 time-boxed).  Every timed leg is followed, outside the timed region, by a PARITY GATE (tests/gates.py): sampled environments
@@ -406,17 +407,20 @@ def learning_and_evaluation(B, w, world, rank):
     if persistent:
         frirl_amd.train_persistent(wprob, wagent, wenvs, max_episodes=3, budget=64)      # untimed: loads the code objects
         del wprob, wenvs
-        for name, diversify, max_episodes in (("learning", False, 1000), ("learning_diversified", True, 200)):
-            start = grid_start_states(dd, LEARN_AGENTS, device, 1 + rank) if diversify else None
-            lprob, lagent, lenvs = frirl_amd.demo_fresh_batch(env, LEARN_AGENTS, 1024, device, start_states=start)
-            lagent.desc.env_id_base = rank * LEARN_AGENTS
+        # the third leg holds four times as many agents as the chip keeps resident at two lanes each (HBM has room for far more): launches stay
+        # full until the very end of the run, where the 65 536-agent leg spends 15 % of its time on its last few thousand agents
+        for name, diversify, max_episodes, NAG in (("learning", False, 1000, LEARN_AGENTS), ("learning_diversified", True, 200, LEARN_AGENTS),
+                                                   ("learning_diversified_4x", True, 200, 4 * LEARN_AGENTS)):
+            start = grid_start_states(dd, NAG, device, 1 + rank) if diversify else None
+            lprob, lagent, lenvs = frirl_amd.demo_fresh_batch(env, NAG, 1024 if NAG == LEARN_AGENTS else 512, device, start_states=start)
+            lagent.desc.env_id_base = rank * NAG
             chunks = []
 
             def on_chunk(i, live, conv):
                 # the report of the many-agent job (reward statistics only).  Ranks with diversified agents make DIFFERENT numbers of
                 # launches, so nothing collective may happen per launch: the statistics are kept locally and cross the GPUs once, below
                 st = torch.stack([lenvs.ep_reward.sum(), lenvs.ep_steps.sum().double(), lprob.nrules.sum().double(), conv.converged.sum().double()])
-                chunks.append((LEARN_AGENTS if live is None else int(live.numel()), st))
+                chunks.append((NAG if live is None else int(live.numel()), st))
             B.sync_all()
             t0 = time.perf_counter()
             run = frirl_amd.train_persistent(lprob, lagent, lenvs, max_episodes=max_episodes, budget=512, on_chunk=on_chunk)
@@ -430,9 +434,9 @@ def learning_and_evaluation(B, w, world, rank):
             tot = tot.tolist()
             slots = tot[4] * (14.4 * (A + 1) + 4.0 * (nant - 1)) + tot[5] * (2.0 * nant + 10.4)
             eps = run.conv.episodes
-            legs[name] = {"value": tot[0] / ldt, "unit": "env-steps/s", "agents": LEARN_AGENTS * world, "start_states": "per-agent, on the state grid" if diversify else "identical (replicas of the demo)",
+            legs[name] = {"value": tot[0] / ldt, "unit": "env-steps/s", "agents": NAG * world, "start_states": "per-agent, on the state grid" if diversify else "identical (replicas of the demo)",
                           "wall_s": ldt, "env_steps": tot[0], "agents_converged": tot[1], "max_episodes": max_episodes,
-                          "episodes_min_max_rank0": [int(eps.min().item()), int(eps.max().item())], "mean_final_rules": tot[2] / (LEARN_AGENTS * world),
+                          "episodes_min_max_rank0": [int(eps.min().item()), int(eps.max().item())], "mean_final_rules": tot[2] / (NAG * world),
                           "agents_with_refused_appends": tot[3], "launches": run.launches, "live_agents_per_launch_rank0": [c[0] for c in chunks][:64],
                           "report_allreduce": {"launches_rank0": len(chunks), "final": dict(zip(["reward_sum", "steps_sum", "rules_sum", "converged"], tot[6:10])),
                                                "note": "one all-reduce per leg: ranks make different numbers of launches"},
@@ -445,7 +449,9 @@ def learning_and_evaluation(B, w, world, rank):
                 eagent = lagent
             del lprob, lenvs, run
             torch.cuda.empty_cache()
-        legs["learning_diversified"]["vs_replicas"] = legs["learning_diversified"]["fp64_issue"]["frac"] / legs["learning"]["fp64_issue"]["frac"]
+        for nm in ("learning_diversified", "learning_diversified_4x"):
+            legs[nm]["vs_replicas"] = legs[nm]["fp64_issue"]["frac"] / legs["learning"]["fp64_issue"]["frac"]      # counted work per second against the replica leg's
+            legs[nm]["vs_replicas_env_steps"] = legs[nm]["value"] / legs["learning"]["value"]
     else:
         # cartpole (21 actions): one episode per launch through the lane groups of lanes.hip; no work counters in that kernel
         lE = 8192
