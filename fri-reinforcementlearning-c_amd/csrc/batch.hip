@@ -25,6 +25,9 @@ struct frirl_hip_batch {
     int32_t *d_spread_R;
     void *d_lanes_ws;            // transposed rule bases of the lane-group kernel (allocated on first use)
     size_t lanes_ws_bytes;
+    void *d_learn_ws;            // workspace of the persistent construct loop, frirl_hip_learn_train (allocated on first use)
+    size_t learn_ws_bytes;
+    int64_t *d_steps_total;      // [E] environment steps of the last frirl_hip_learn_train
     int32_t *d_nrules, *d_fus, *d_done, *d_ep_steps, *d_status, *d_episode, *d_prev_nrules, *d_prev_steps, *d_converged, *d_episodes, *d_epended;
     frirl_hip_tables t;
     frirl_hip_rulebases rb;
@@ -86,7 +89,7 @@ extern "C" void frirl_hip_batch_destroy(frirl_hip_batch *b)
     if (b->s) (void)hipStreamSynchronize(b->s);
     void *ptrs[] = {b->d_u, b->d_ve, b->d_rb, b->d_rant, b->d_grid, b->d_ave, b->d_states, b->d_q_ant, b->d_ep_reward, b->d_start, b->d_prev_reward,
                     b->d_prev_rconc, b->d_tmp, b->d_nrules, b->d_fus, b->d_done, b->d_ep_steps, b->d_status, b->d_episode, b->d_prev_nrules,
-                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_epended, b->d_uidx, b->d_lanes_ws, b->d_weights, b->d_active, b->d_full, b->d_spread_ant, b->d_spread_R};
+                    b->d_prev_steps, b->d_converged, b->d_episodes, b->d_epended, b->d_uidx, b->d_lanes_ws, b->d_learn_ws, b->d_steps_total, b->d_weights, b->d_active, b->d_full, b->d_spread_ant, b->d_spread_R};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->s) (void)hipStreamDestroy(b->s);
     delete b;
@@ -198,10 +201,47 @@ extern "C" int frirl_hip_batch_episode(frirl_hip_batch *b)
     return check_launch("frirl_hip_batch_episode");
 }
 
+// The whole construct loop on the device (frirl_hip_learn_train) where the persistent learner covers the shape: every agent runs its
+// episodes at its own pace instead of the batch waiting for its longest episode, launch after launch.  Same agents, same results
+// (both forms follow the reference's loop per agent); *episodes_run = the largest number of episodes an agent ran in this call.
+static int batch_train_persistent(frirl_hip_batch *b, int32_t max_episodes, int32_t *episodes_run)
+{
+    const size_t E = (size_t)b->E;
+    b->h_i.resize(2 * E);
+    BCHK(hipMemcpy(b->h_i.data(), b->d_episodes, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "episodes download");
+    BCHK(hipMemcpy(b->h_i.data() + E, b->d_converged, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "converged download");
+    int before = 0;
+    bool all = true;
+    for (size_t e = 0; e < E; e++) if (!b->h_i[E + e]) { all = false; before = std::max(before, b->h_i[e]); }
+    if (episodes_run) *episodes_run = 0;
+    if (all || max_episodes < 2) return FRIRL_HIP_OK;
+    if (!b->d_learn_ws) {
+        b->learn_ws_bytes = frirl_hip_learn_train_workspace_bytes(b->nant, b->E, b->maxR, b->agent.A);
+        BCHK(hipMalloc(&b->d_learn_ws, b->learn_ws_bytes), "learner workspace");
+        BCHK(hipMalloc((void **)&b->d_steps_total, sizeof(int64_t) * E), "learner step counters");
+    }
+    BCHK(hipMemsetAsync(b->d_steps_total, 0, sizeof(int64_t) * E, b->s), "step counters");
+    BCHK(hipMemsetD32Async((hipDeviceptr_t)b->d_done, 1, E, b->s), "episode flags");       // every agent is between two episodes here
+    // agents that are still learning have all run `before` episodes (the per-episode form keeps them in step): up to max_episodes - 1 more
+    int32_t launches = 0;
+    int rc = frirl_hip_learn_train(&b->t, &b->rb, &b->agent, &b->envs, &b->conv, 512, max_episodes + before, nullptr, b->d_steps_total, nullptr,
+                                   b->d_learn_ws, b->learn_ws_bytes, &launches, nullptr, nullptr, b->s);
+    if (rc) return rc;
+    std::vector<int64_t> st(E);
+    BCHK(hipMemcpy(st.data(), b->d_steps_total, sizeof(int64_t) * E, hipMemcpyDeviceToHost), "steps download");
+    BCHK(hipMemcpy(b->h_i.data(), b->d_episodes, sizeof(int32_t) * E, hipMemcpyDeviceToHost), "episodes download");
+    int after = before;
+    for (size_t e = 0; e < E; e++) { b->total_env_steps += st[e]; after = std::max(after, b->h_i[e]); }
+    if (episodes_run) *episodes_run = after - before;
+    return FRIRL_HIP_OK;
+}
+
 extern "C" int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *episodes_run)
 {
     if (!b) { set_error("frirl_hip_batch_train: NULL batch"); return FRIRL_HIP_EINVAL; }
     DeviceGuard keep_device_; BCHK(hipSetDevice(b->device), "hipSetDevice");
+    if (!b->agent.evaluate && b->d_uidx && frirl_hip_learn_supported(b->nant, b->U, b->agent.A, b->agent.p, b->agent.env_kind))
+        return batch_train_persistent(b, max_episodes, episodes_run);
     int ep = 0;
     for (ep = 1; ep < max_episodes; ep++) {             // at most max_episodes-1 episodes (frirl_sequential_run.c:51,59)
         int rc = frirl_hip_batch_episode(b);

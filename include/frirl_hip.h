@@ -484,7 +484,9 @@ void frirl_hip_batch_destroy(frirl_hip_batch *b);
 /* one episode for every not-yet-converged agent (frirl_episode), then the convergence bookkeeping */
 int frirl_hip_batch_episode(frirl_hip_batch *b);
 /* frirl_sequential_run's construct loop for all agents: at most max_episodes-1 episodes, stops when every agent's
- * rule base is "considered complete"; *episodes_run receives the number of episodes executed */
+ * rule base is "considered complete"; *episodes_run receives the number of episodes executed (the most any agent ran).  Shapes the
+ * persistent learner covers (frirl_hip_learn_supported) run through frirl_hip_learn_train -- every agent at its own pace; the others
+ * episode by episode (frirl_hip_batch_episode).  Same results per agent either way. */
 int frirl_hip_batch_train(frirl_hip_batch *b, int32_t max_episodes, int32_t *episodes_run);
 int frirl_hip_batch_stats(frirl_hip_batch *b, frirl_hip_batch_stats_t *out);
 /* rule base of agent e: *R rules, rant HOST [>= *R][nant] (AoS), rconc HOST [>= *R] (pass NULL to query *R only) */
