@@ -166,7 +166,7 @@ struct Options {
     int rollout_resident; // shared-base roll-out: 0 = never the LDS-resident queue-fed form (rollout.hip), -1 = by shape (FRIRL_HIP_ROLLOUT_RESIDENT)
     int rollout_cap;      // resident roll-out: steps before a long episode is parked for the latency form, 0 = max_steps / 6 (FRIRL_HIP_ROLLOUT_CAP)
     int rollout_pair;     // resident roll-out, one environment per wave: 0 = the one-wave form instead of sweeper + speculative stepper (FRIRL_HIP_ROLLOUT_PAIR)
-    int rollout_wps;      // resident roll-out: persistent waves per SIMD, 1 or 2 (0 = 2)             (FRIRL_HIP_ROLLOUT_WPS)
+    int rollout_wps;      // resident roll-out: persistent waves per SIMD, 1 ... 4 (0 = 2, or 4 for queue-fed launches) (FRIRL_HIP_ROLLOUT_WPS)
     int learn_slices;     // persistent learner: lanes per agent 4 / 16 / 64, 0 = by the number of live agents (FRIRL_HIP_LEARN_SLICES)
     int learn_alone;      // learner launch plan: cost factor (tenths) of a wave that has its SIMD to itself, 0 = 20 (FRIRL_HIP_LEARN_ALONE)
     int learn_persistent; // 0: frirl_hip_learn_supported answers no (callers fall back to one episode per launch) (FRIRL_HIP_LEARN_PERSISTENT)

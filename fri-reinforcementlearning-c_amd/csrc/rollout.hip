@@ -261,27 +261,60 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void rollout_resident_kernel(const dou
                 }
                 sh[a] = f;
             }
-#pragma unroll 2
-            for (int j = 0; j < nj; j++) {
-                const int r = j * H + h;
-                const double *rule = col + r * (NANT + 1);
-                const double d0 = q[0] - rule[0];
-                double s = d0 * d0;
+            // Two rules in flight.  A rule's LDS reads are issued right after the first instructions of the PREVIOUS rule's arithmetic -- the ones
+            // that consume every value that rule read -- so that the compiler's wait for "everything outstanding" (it does not emit partial
+            // LDS waits across this loop's back edge) falls where only reads issued a whole rule ago are outstanding.  The scheduling
+            // barriers pin that order; without them the two rules' arithmetic is interleaved and both reads are waited for at once
+            // (65 536 acrobot roll-outs 9.1 -> 8.3 ms).
+            struct Open { double d[NS], va, cq; };
+            auto fetch = [&](double (&x)[NANT + 1], int jj) {
+                const double *rule = col + (jj * H + h) * (NANT + 1);
 #pragma unroll
-                for (int k = 1; k < NS; k++) { const double d = q[k] - rule[k]; s = __fma_rn(d, d, s); }
-                const double va = rule[NS], cq = rule[NANT];
+                for (int k = 0; k <= NANT; k++) x[k] = rule[k];
+            };
+            auto open = [&](const double (&rule)[NANT + 1]) {              // touches every value of the row
+                Open o;
+#pragma unroll
+                for (int k = 0; k < NS; k++) o.d[k] = q[k] - rule[k];
+                o.va = rule[NS]; o.cq = rule[NANT];
+                return o;
+            };
+            auto close = [&](const Open &o, int jj) {
+                double s = o.d[0] * o.d[0];
+#pragma unroll
+                for (int k = 1; k < NS; k++) s = __fma_rn(o.d[k], o.d[k], s);
                 if (EXCL) {                               // a removed rule weighs exactly 0 (same sums as the compacted rule base)
-                    const unsigned sl = slot_s[r];
+                    const unsigned sl = slot_s[jj * H + h];
                     s = (sl < 32u && ((mask >> sl) & 1u)) ? NO_RULE_STATE_PART : s;
                 }
 #pragma unroll
                 for (int a = 0; a < NA; a++) {
-                    const double e = ave[a] - va;
+                    const double e = ave[a] - o.va;
                     const double d2 = __fma_rn(e, e, s);
                     const double wi = shepard_w(d2, pk);
-                    sv[a] = __fma_rn(wi, cq, sv[a]);
+                    sv[a] = __fma_rn(wi, o.cq, sv[a]);
                     sw[a] = sw[a] + wi;
                 }
+            };
+            if (nj > 0) {
+                double ra[NANT + 1], rb2[NANT + 1];
+                fetch(ra, 0);
+                int j = 0;
+                for (; j + 1 < nj; j += 2) {
+                    const Open oa = open(ra);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch(rb2, j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    close(oa, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const Open ob = open(rb2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch(ra, j + 2 < nj ? j + 2 : nj - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    close(ob, j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (j < nj) { const Open oa = open(ra); close(oa, j); }
             }
         }
         if (H > 1) {                                      // combine the H rule slices (all lanes of the wave take part in the moves)
@@ -623,7 +656,10 @@ void launch_phase_h(int H, bool excl, const frirl_hip_tables *t, const frirl_hip
         const size_t pdyn = (size_t)(N + 1) * ph.rps * sizeof(double) + (KIND != FRIRL_HIP_ENV_CARTPOLE ? 2 * sizeof(double) * N * (size_t)t->U : 0) + sizeof(uint32_t) * (size_t)ph.ht + (excl ? (size_t)ph.rps : 0);
         const long pcu = (long)((150 * 1024) / (pdyn + 4096));
         const long pcap = (pcu < 1 ? 1 : (pcu > 8 ? 8 : pcu)) * device_cus();
-        if (H >= 64 && opts().rollout_pair != 0 && (ph.from_parked || (long)items_max <= pcap || opts().rollout_pair == 1)) {
+        // (acrobot's own dynamics are the longer half of a step and its never-succeeding episodes a 1000-step chain: there the two-wave form
+        // wins even in several rounds -- 2 000 fresh environments 3.2 vs 5.2 ms; mountaincar's trivial step gains nothing: 3.2 vs 2.3 ms)
+        const bool long_step = KIND == FRIRL_HIP_ENV_ACROBOT && !excl;
+        if (H >= 64 && opts().rollout_pair != 0 && (ph.from_parked || (long)items_max <= pcap || long_step || opts().rollout_pair == 1)) {
             if (excl) launch_pair<N, NA, KIND, true>(t, b, ag, Q, ro, ctl, src, ph, items_max, s);
             else launch_pair<N, NA, KIND, false>(t, b, ag, Q, ro, ctl, src, ph, items_max, s);
             return;
@@ -694,7 +730,9 @@ int frirl_rollout_resident(const frirl_hip_tables *t, const frirl_hip_rulebases 
         list[i].act = list[i].steps + q8;
     }
     const Options &o = opts();
-    const int wps = (o.rollout_wps >= 1 && o.rollout_wps <= 4) ? o.rollout_wps : 2;
+    // persistent waves per SIMD: 2 when that keeps every environment resident (65 536 at 2 lanes each: 8.5 / 8.6 / 8.9 ms with 2 / 3 / 4), 4 when the
+    // launch is queue-fed anyway (262 144 environments 26.3 -> 21.8 ms, a million 76.5 -> 70.6 ms: more waves hide what the step outside the rule loop waits for)
+    const int wps = (o.rollout_wps >= 1 && o.rollout_wps <= 4) ? o.rollout_wps : ((long)Q * 2 > (long)device_cus() * 4 * 2 * FRIRL_WAVE ? 4 : 2);
     const long lanes = (long)device_cus() * 4 * wps * FRIRL_WAVE;
     frirl::RolloutPhase ph = {};
     ph.rps = rps;
