@@ -11,12 +11,13 @@ static long learn_lanes()
     return (long)cus * 4 * 2 * FRIRL_WAVE;              // two waves per SIMD (the kernels' register budget)
 }
 
-// lanes per agent for a launch of EXACTLY nlive agents: the largest power of two that keeps all of them resident (2 ... 64)
+// lanes per agent for a launch of EXACTLY nlive agents: the largest power of two that keeps all of them resident (1 ... 64; one lane per
+// agent when more than half the chip's lanes' worth of agents are alive: nothing of a step is then computed twice)
 static int learn_slices(int nlive)
 {
-    { const int v = opts().learn_slices; if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v; }
+    { const int v = opts().learn_slices; if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v; }
     const long lanes = learn_lanes();
-    int H = 2;
+    int H = 1;
     while (H < 64 && (long)nlive * (2 * H) <= lanes) H *= 2;
     return H;
 }
@@ -24,7 +25,7 @@ static int learn_slices(int nlive)
 // How many of `nlive` agents that are still learning the next launch should take, and with how many lanes each.  A launch is at its
 // best when it fills the chip (two waves per SIMD); with H lanes per agent that takes lanes / H agents.  The more lanes an agent
 // has, the larger the share of a step that is not rule work (the environment's own dynamics, ~1000 instructions, and the butterfly),
-// so the plan maximises  occupancy(H) x rule-work share(H)  over H = 2 ... 64 -- and when more agents are alive than fill the chip at
+// so the plan maximises  occupancy(H) x rule-work share(H)  over H = 1 ... 64 -- and when more agents are alive than fill the chip at
 // that H, the launch takes the first lanes / H of them and the caller rotates the rest to the front of the next launch (every
 // launch full, instead of the half-empty launches a fixed assignment gives between two powers of two).
 extern "C" int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *slices, int32_t *agents_per_launch)
@@ -41,7 +42,7 @@ extern "C" int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *
     const double simds = (double)lanes / (2.0 * FRIRL_WAVE);
     int bestH = 2;
     double best = -1.0;
-    for (int H = 2; H <= 64; H *= 2) {
+    for (int H = 1; H <= 64; H *= 2) {
         int lg = 0;
         for (int h = H; h > 1; h >>= 1) lg++;
         const double wave_step = 5200.0 + R * 93.0 / H + 40.0 * lg;
@@ -52,7 +53,7 @@ extern "C" int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *
         const double score = agents / (wave_step * share);                                    // agent-steps per unit of time
         if (score > best) { best = score; bestH = H; }
     }
-    { const int v = opts().learn_slices; if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) bestH = v; }
+    { const int v = opts().learn_slices; if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) bestH = v; }
     const long cap = lanes / bestH;
     *slices = bestH;
     *agents_per_launch = (int32_t)((long)nlive < cap ? nlive : cap);
@@ -80,7 +81,7 @@ extern "C" size_t frirl_hip_learn_workspace_bytes(int32_t nant, int32_t E, int32
 {
     if (nant < 1 || E < 1 || maxR < 1 || A < 1) return 0;
     size_t m = 0;
-    for (int H : {2, 4, 8, 16, 32, 64}) { const size_t n = learn_entries(E, maxR, H); m = n > m ? n : m; }
+    for (int H : {1, 2, 4, 8, 16, 32, 64}) { const size_t n = learn_entries(E, maxR, H); m = n > m ? n : m; }
     return m * (16 + 8 + 8) + 256;
 }
 

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     __shared__ double grid_s[NANT * FRIRL_HIP_MAX_GRID];
     __shared__ double udiv[8];                                                // FIVEInit.c:244-248, once instead of per observation
     __shared__ unsigned aidx_s[NA];                                           // universe index of every action value
-    __shared__ double cold_s[LR_WPB * (FRIRL_WAVE / H) * NCOLD];
+    extern __shared__ __attribute__((aligned(16))) double cold_s[];          // [LR_WPB * EPW][NCOLD]: dynamic (51 KB at one lane per agent: beyond the static limit)
     __shared__ uint32_t mask_s[LR_MW * LR_BLOCK];                             // [word][thread]: spread candidates of the sweep (see `thr`)
     static_assert(32 % (2 * UR) == 0, "a flag word is filled by whole loop iterations");
     const int U = la.U, maxR = la.maxR;
@@ -688,7 +688,12 @@ inline void launch_learn(const frirl_hip_tables *t, const frirl_hip_rulebases *b
     la.Tp = la.Tq + n;
     la.sum_rules = reinterpret_cast<long long *>(la.Tp + n);                  // inside the 256 B the workspace size adds at its end
     (void)hipMemsetAsync(la.sum_rules, 0, sizeof(long long), s);
-    const size_t dyn = 0;
+    constexpr int NCOLD_ = 2 * (N - 1) + 2 * N + 3 + 4;                        // = learn_kernel's NCOLD
+    const size_t dyn = sizeof(double) * frirl::LR_WPB * EPW * NCOLD_;
+    if (dyn > 40 * 1024) {                                                     // static (~24 KB) + dynamic beyond the 64 KB default
+        static bool raised = false;                                            // per instantiation
+        if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(frirl::learn_kernel<N, NA, KIND, H, BITS, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); raised = true; }
+    }
     hipLaunchKernelGGL((frirl::learn_import_kernel<N, BITS>), dim3(la.tiles), dim3(256), 0, s, la, H, cv->prev_rconc);
     const int blocks = (la.tiles + frirl::LR_WPB - 1) / frirl::LR_WPB;
     hipLaunchKernelGGL((frirl::learn_kernel<N, NA, KIND, H, BITS, WPS>), dim3(blocks), dim3(frirl::LR_BLOCK), dyn, s, la, *ag, *ev, *cv);
@@ -702,6 +707,7 @@ template <int N, int NA, int KIND, int BITS, int WPS, int HLO, int HHI>
 inline void launch_learn_h(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
                            const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s)
 {
+    if constexpr (HLO <= 1 && 1 <= HHI) if (H == 1) return launch_learn<N, NA, KIND, 1, BITS, WPS>(t, b, ag, ev, cv, la, s);
     if constexpr (HLO <= 2 && 2 <= HHI) if (H == 2) return launch_learn<N, NA, KIND, 2, BITS, WPS>(t, b, ag, ev, cv, la, s);
     if constexpr (HLO <= 4 && 4 <= HHI) if (H == 4) return launch_learn<N, NA, KIND, 4, BITS, WPS>(t, b, ag, ev, cv, la, s);
     if constexpr (HLO <= 8 && 8 <= HHI) if (H == 8) return launch_learn<N, NA, KIND, 8, BITS, WPS>(t, b, ag, ev, cv, la, s);

@@ -338,7 +338,7 @@ int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_ruleb
  * change what the agent computes)
  * (:51,59).  Nothing in a launch waits for the longest episode of the batch: the reference's many-agent modes diversify the start
  * states (frirl_agent.c:121-139), so agents are never in step.  Between calls the host compacts the agents that are still learning
- * into `live`; the fewer they are, the more lanes each gets (2 ... 64 rule slices per agent: the largest power of two that keeps all of them resident).
+ * into `live`; the fewer they are, the more lanes each gets (1 ... 64 rule slices per agent: the largest power of two that keeps all of them resident; one lane per agent when more than 65 536 are alive on a 256-CU chip).
  * State: envs->done[e] != 0 on entry means "between two episodes" (set it to 1 for a fresh agent; frirl_hip_convergence_init first);
  * on return done[e] = 1 iff the agent stopped at an episode boundary, ep_steps / ep_reward = the running or last episode,
  * conv->episodes / converged / prev_* as frirl_hip_convergence_update leaves them, status[e] = FRIRL_HIP_UPD_FULL iff an append was

@@ -25,7 +25,7 @@ def check_agent_against_oracle(fr, prob, envs, e):
     assert (ui == f.uidx[:, :R]).all(), f"agent {e}: index mirror"
 
 
-@pytest.mark.parametrize("slices", [0, 2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("slices", [0, 1, 2, 4, 8, 16, 32, 64])
 @pytest.mark.parametrize("env,episodes,steps,rules", [("mountaincar", 29, 15548, 110), ("acrobot", 110, 21207, 367)])
 def test_persistent_training_reaches_the_oracle_rule_base(env, episodes, steps, rules, slices, hip_option):
     """E = 21 replicas of the demo (ragged last wave), launches of 700 steps (every agent is stopped and resumed in the middle of
