@@ -259,6 +259,9 @@ __global__ __launch_bounds__(BLOCK) void episode_begin_kernel(const double *__re
 #ifndef FRIRL_STEP_WAVES_N3
 #define FRIRL_STEP_WAVES_N3 6
 #endif
+#ifndef FRIRL_STEP_SAME_CELL
+#define FRIRL_STEP_SAME_CELL 1     // 0: always the full pending distance (A/B builds)
+#endif
 constexpr int step_min_waves(int nant, int amax) { return (nant <= 3 && amax <= 4) ? FRIRL_STEP_WAVES_N3 : (amax > 8 ? 3 : 4); }
 
 // TRACK: the candidates of update_rules' write-back are collected during the fused sweep (sweeps.h: SpreadCand) -- for LARGE rule
@@ -319,7 +322,14 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     int ap;
     if constexpr (AMAX == 24) ap = sweep_gba_many<NANT, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn);
     else if constexpr (AMAX > 8) ap = sweep_gba_wide<NANT, 8, AMAX, BLOCK, true, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn, ag.weight_significant, cand_s);
-    else ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
+    else {
+        // the agent has not left its quantisation cell (workgroup-uniform): the pending conclusion shares the greedy sweep's state part
+        bool same_cell = NS > 0 && FRIRL_STEP_SAME_CELL != 0;
+#pragma unroll
+        for (int k = 0; k < NS; k++) same_cell = same_cell && (q[k] == q1[k]);
+        if (same_cell) ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
+        else ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK, false>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
+    }
 #ifdef FRIRL_STEP_TIMING
     const long long tm1 = wall_clock64();
 #endif
