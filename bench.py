@@ -314,8 +314,14 @@ class Bench:
         # parity gate, outside the timed region: ONE more step of the whole batch; sampled environments replayed by the oracle from a
         # snapshot (state, chosen action, rule count and appended antecedents exact, consequents <= 1e-9)
         from tests import gates
+        ns = nant - 1
+        cell_before = envs.q_ant[:, :ns].clone()
+        running = envs.done == 0
         gate = gates.gate_env_step(prob, agent, envs, w["env"], gates.spread_sample(E, 8, boundaries=(E // 4,)),
                                    lambda: frirl_amd.episode_step(prob, agent, envs, stream=self.stream))
+        # environments that did not leave their quantisation cell in that step: the fused sweep of the 3-action shapes then forms the pending
+        # conclusion's distance from the greedy sweep's state part (sweeps.h: SAMES) -- 2 (nant - 1) slots per rule less; the slot model follows
+        same_cell = float(((cell_before == envs.q_ant[:, :ns]).all(1) & running).double().sum() / running.double().sum().clamp(min=1.0)) if w["A"] <= 8 else 0.0
         # per-episode reward statistics: the ONLY cross-rank exchange (RCCL all-reduce over xGMI when N > 1)
         st = self.D.allreduce_stats(envs.ep_reward, envs.ep_steps, envs.done, prob.nrules)
         status = torch.bincount(envs.status.long(), minlength=6).tolist()
@@ -326,7 +332,7 @@ class Bench:
                "moved_bytes_per_step": moved, "moved_GBps": moved / (ems * 1e-3) / 1e9, "moved_frac": moved / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "contract_bytes_per_step": float(E) * (2.0 * R * (nant + 1) * 8 + R * 8),    # SURVEY 8d U2 (the reference's three sweeps, f64)
                "rule_action_evals_per_s": float(E) * R * (w["A"] + 1) / (ems * 1e-3),
-               "fp64_issue": fp64_issue(E, R, nant, w["A"], ems, name),
+               "fp64_issue": fp64_issue(E, R, nant, w["A"], ems, name, same_cell),
                "stats_allreduce": {"envs": st.envs, "mean_reward": st.mean_reward, "mean_rules": st.mean_rules, "steps_sum": st.steps_sum,
                                    "episodes_done": st.success, "reward_min": st.reward_min, "reward_max": st.reward_max},
                "last_step_outcomes_rank0": dict(zip(["inactive", "exact", "spread", "inserted", "skipped", "full"], status)),
@@ -340,12 +346,13 @@ class Bench:
 FP64_VECTOR_PEAK_TFLOPS = 78.6        # MI355X FP64 vector peak (FMA = 2 flop): 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x 2
 
 
-def fp64_issue(E, R, nant, A, ms, name=None):
+def fp64_issue(E, R, nant, A, ms, name=None, same_cell=0.0):
     """FP64-issue roofline of the fused step.  Algorithmic slots per rule (one slot = one FP64 vector instruction of one lane;
     v_rsq_f64 issues in 3.4 slots, profiles/r02_valu_cost.txt): per conclusion (A greedy + 1 pending) 2 for the squared distance,
     3.4 + 7 for the Shepard weight (rsq + series + power, sweeps.h: shepard_series), 2 for the two sums = 14.4; plus the state part
-    (sub + fma per state dimension) and the rest of the pending update's full distance."""
-    slots_per_rule = 14.4 * (A + 1) + 2.0 * (nant - 1) + 2.0 * (nant - 1)
+    (sub + fma per state dimension) and the rest of the pending update's full distance -- which the kernel does not compute for the
+    `same_cell` share of the environments (measured on the gate step: they did not leave their quantisation cell)."""
+    slots_per_rule = 14.4 * (A + 1) + 2.0 * (nant - 1) + 2.0 * (nant - 1) * (1.0 - same_cell)
     peak = FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0          # lane-instructions per second
     achieved = float(E) * R * slots_per_rule / (ms * 1e-3)
     counted = None
@@ -358,7 +365,7 @@ def fp64_issue(E, R, nant, A, ms, name=None):
                        "note": "SQ_INSTS_VALU x 64 from the committed PMC pass / THIS run's launch time: every VALU instruction (FP64, integer, address) counts once"}
     except (OSError, ValueError, KeyError):
         pass
-    return {"slots_per_rule": slots_per_rule, "achieved_lane_instr_per_s": achieved, "peak_lane_instr_per_s": peak, "frac": achieved / peak, "counted": counted,
+    return {"slots_per_rule": slots_per_rule, "same_cell_share": same_cell, "achieved_lane_instr_per_s": achieved, "peak_lane_instr_per_s": peak, "frac": achieved / peak, "counted": counted,
             "how": "frac = slot MODEL (algorithmic FP64 slots of the fused sweep / launch time / peak); counted = the same launch priced by the SQ_INSTS_VALU counter",
             "peak_source": "FP64 vector 78.6 TFLOP/s (half the FP32 vector peak of MI355X_MICROARCH.md: 16 lanes per clock and SIMD at 2.4 GHz) = 3.93e13 lane-instructions/s; a v_fma_f64 stream alone reaches 0.82 of it (profiles/r02_valu_cost.txt)"}
 
