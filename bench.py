@@ -319,8 +319,8 @@ class Bench:
         running = envs.done == 0
         gate = gates.gate_env_step(prob, agent, envs, w["env"], gates.spread_sample(E, 8, boundaries=(E // 4,)),
                                    lambda: frirl_amd.episode_step(prob, agent, envs, stream=self.stream))
-        # environments that did not leave their quantisation cell in that step: the fused sweep of the 3-action shapes then forms the pending
-        # conclusion's distance from the greedy sweep's state part (sweeps.h: SAMES) -- 2 (nant - 1) slots per rule less; the slot model follows
+        # environments that did not leave their quantisation cell in that step: the fused sweep of the 3-action shapes then takes the pending
+        # conclusion from the greedy sweep's conclusion of the pending action (sweeps.h: SAMES); the slot model counts only what is computed
         same_cell = float(((cell_before == envs.q_ant[:, :ns]).all(1) & running).double().sum() / running.double().sum().clamp(min=1.0)) if w["A"] <= 8 else 0.0
         # per-episode reward statistics: the ONLY cross-rank exchange (RCCL all-reduce over xGMI when N > 1)
         st = self.D.allreduce_stats(envs.ep_reward, envs.ep_steps, envs.done, prob.nrules)
@@ -350,9 +350,10 @@ def fp64_issue(E, R, nant, A, ms, name=None, same_cell=0.0):
     """FP64-issue roofline of the fused step.  Algorithmic slots per rule (one slot = one FP64 vector instruction of one lane;
     v_rsq_f64 issues in 3.4 slots, profiles/r02_valu_cost.txt): per conclusion (A greedy + 1 pending) 2 for the squared distance,
     3.4 + 7 for the Shepard weight (rsq + series + power, sweeps.h: shepard_series), 2 for the two sums = 14.4; plus the state part
-    (sub + fma per state dimension) and the rest of the pending update's full distance -- which the kernel does not compute for the
-    `same_cell` share of the environments (measured on the gate step: they did not leave their quantisation cell)."""
-    slots_per_rule = 14.4 * (A + 1) + 2.0 * (nant - 1) + 2.0 * (nant - 1) * (1.0 - same_cell)
+    (sub + fma per state dimension) and the rest of the pending update's full distance.  For the `same_cell` share of the environments
+    (measured on the gate step: they did not leave their quantisation cell) the kernel does not compute the pending conclusion at all --
+    it IS the greedy conclusion of the pending action -- so neither its 14.4 slots nor its state part are counted."""
+    slots_per_rule = 14.4 * (A + 1) + 4.0 * (nant - 1) - same_cell * (14.4 + 2.0 * (nant - 1))
     peak = FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0          # lane-instructions per second
     achieved = float(E) * R * slots_per_rule / (ms * 1e-3)
     counted = None

@@ -323,11 +323,14 @@ __global__ __launch_bounds__(BLOCK, step_min_waves(NANT, AMAX)) void episode_ste
     if constexpr (AMAX == 24) ap = sweep_gba_many<NANT, AMAX, BLOCK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn);
     else if constexpr (AMAX > 8) ap = sweep_gba_wide<NANT, 8, AMAX, BLOCK, true, TRACK>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, &rn, ag.weight_significant, cand_s);
     else {
-        // the agent has not left its quantisation cell (workgroup-uniform): the pending conclusion shares the greedy sweep's state part
+        // the agent has not left its quantisation cell (workgroup-uniform): Q(s, a) of the pending update is the greedy sweep's conclusion
+        // for action a at the new observation (sweeps.h: SAMES)
         bool same_cell = NS > 0 && FRIRL_STEP_SAME_CELL != 0;
 #pragma unroll
         for (int k = 0; k < NS; k++) same_cell = same_cell && (q[k] == q1[k]);
-        if (same_cell) ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
+        int apend = -1;
+        for (int a = ag.A - 1; a >= 0; a--) if (gs.ave[a] == q1[NS]) apend = a;
+        if (same_cell && apend >= 0) ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK, true>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s, apend);
         else ap = sweep_gba_q<NANT, AMAX, BLOCK, TRACK, false>(cols, qcol, nrules[e], q, q1, pw, ag.A, gs, red, rn, ag.weight_significant, cand_s);
     }
 #ifdef FRIRL_STEP_TIMING

@@ -508,6 +508,7 @@ struct GbaScratch {
     unsigned hit[AMAX];         // first exact hit per action, recorded by note_state_hits (atomic min)
     double actconc[AMAX];
     double ave[AMAX];
+    double tv[AMAX], tw[AMAX];  // the actions' reduced Shepard sums (sweep_gba_q: the pending conclusion of a same-cell step reads its action's)
     int best;
 };
 
@@ -525,6 +526,18 @@ __device__ __forceinline__ void concl_pair_nohit(double av, const double2 &va, d
     const double e0 = av - va.x, e1 = av - va.y;
     const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);
     const double w0 = shepard_w(d0, p), w1 = shepard_w(d1, p);
+    sv = __fma_rn(w0, c.x, sv);
+    sw = sw + w0;
+    sv = __fma_rn(w1, c.y, sv);
+    sw = sw + w1;
+}
+template <class POW>
+__device__ __forceinline__ void concl_pair_nohit(double av, const double2 &va, double s0, double s1, const double2 &c, POW p, double &sv, double &sw, double &w0,
+                                                 double &w1)
+{
+    const double e0 = av - va.x, e1 = av - va.y;
+    const double d0 = __fma_rn(e0, e0, s0), d1 = __fma_rn(e1, e1, s1);
+    w0 = shepard_w(d0, p); w1 = shepard_w(d1, p);
     sv = __fma_rn(w0, c.x, sv);
     sw = sw + w0;
     sv = __fma_rn(w1, c.y, sv);
@@ -609,13 +622,15 @@ __device__ int sweep_gba(const COLS &cols, const double *__restrict__ qcol, int 
 // instead of twice that.  Per-lane accumulation order and the reduction tree are those of the two separate
 // sweeps, so every result is bit-identical to running them one after the other.
 // SAMES: the caller has found the pending observation's state part identical to the new observation's (the agent has not left its
-// quantisation cell: 62 % of acrobot's steps, 84 % of mountaincar's) -- the pending conclusion's squared distance is then the greedy
-// sweep's state part plus its own action term, the SAME operations in the same order as the full sum (bit-identical), 2 (nant - 1)
-// FP64 instructions per rule less.
+// quantisation cell: 62 % of acrobot's steps, 84 % of mountaincar's).  The pending point (s, a) is then the new observation with action
+// `apend` = a: Q(s, a) IS the greedy sweep's conclusion for that action over the same rule base -- its exact hit, its Shepard sums and
+// (TRACK) its per-rule weights are taken from there, and the pending conclusion is not computed at all: 14.4 + 2 (nant - 1) FP64
+// instructions per rule less.  Per-lane sums are the same operations in the same order as the separate pending sums; they are
+// combined in the greedy sweep's reduction order (wave butterfly, then waves) instead of the block tree: Q(s, a) within ~1e-16 relative.
 template <int NANT, int AMAX, int BLOCK, bool TRACK = false, bool SAMES = false, class COLS, class POW>
 __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, int R, const double (&qs_in)[NANT - 1 > 0 ? NANT - 1 : 1],
                            const double (&q1_in)[NANT], POW p, int A, GbaScratch<AMAX, BLOCK> &s, BlockRed<BLOCK> &red, QResult &qres, double track_thr = 0.0,
-                           SpreadCand *slot = nullptr)
+                           SpreadCand *slot = nullptr, int apend = 0)
 {
     constexpr int NS = NANT - 1;
     // the two observations are wave-uniform: in scalar registers they cost the sweep no VGPRs (a VOP3 reads one scalar operand)
@@ -705,19 +720,19 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
                 }
             }
             double2 va = v[NS];
-            if constexpr (SAMES) {
-                // (1') Q(s,a) from the shared state part: s + (a - va)^2, the last term of the full sum
-                const double d0 = q1[NS] - va.x, d1 = q1[NS] - va.y;
-                const double a0 = __fma_rn(d0, d0, s0);
-                double a1 = __fma_rn(d1, d1, s1);
-                if (!second) { a1 = NO_RULE_STATE_PART; c.y = 0.0; }
-                q_pair(a0, a1, c, (unsigned)r, pk, qbest, qv, qw, tw0, tw1);
-            }
             if (!second) { s1 = NO_RULE_STATE_PART; va.y = 0.0; c.y = 0.0; }
             note_state_hits(s.hit, s.ave, A, s0, s1, va, (unsigned)r);
 #pragma unroll
             for (int a = 0; a < AMAX; a++)
-                if (a < A) concl_pair_nohit(av[a], va, s0, s1, c, pk, sv[a], sw[a]);
+                if (a < A) {
+                    if constexpr (SAMES && TRACK) {
+                        double w0, w1;
+                        concl_pair_nohit(av[a], va, s0, s1, c, pk, sv[a], sw[a], w0, w1);
+                        if (a == apend) { tw0 = w0; tw1 = w1; qw = sw[a]; }      // uniform: the pending conclusion's weights and running sum
+                    } else {
+                        concl_pair_nohit(av[a], va, s0, s1, c, pk, sv[a], sw[a]);
+                    }
+                }
         }
         if constexpr (SAMES) { if (TRACK) spread_track(slot, T, track_thr, tw0, tw1, (unsigned)r, qw); }
     };
@@ -728,9 +743,11 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
             if (ru < r_lim) rule_pair(ru, nraw[u], nc[u]);       // tracked form: wave-uniform (r_lim is a multiple of 128)
         }
     }
-    qres.hit = blk_min<BLOCK>(qbest, red);
-    qres.vagc = blk_sum<BLOCK>(qv, red);
-    qres.ws = blk_sum<BLOCK>(qw, red);
+    if constexpr (!SAMES) {
+        qres.hit = blk_min<BLOCK>(qbest, red);
+        qres.vagc = blk_sum<BLOCK>(qv, red);
+        qres.ws = blk_sum<BLOCK>(qw, red);
+    }
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
     wave_sum_f64_n(sv);                              // the 2 AMAX butterflies in one pass (device_common.h)
     wave_sum_f64_n(sw);
@@ -744,8 +761,10 @@ __device__ int sweep_gba_q(const COLS &cols, const double *__restrict__ qcol, in
         for (int w = 1; w < GbaScratch<AMAX, BLOCK>::WAVES; w++) { tv = tv + s.v[w][a]; tw = tw + s.w[w][a]; }
         const unsigned th = s.hit[a];                   // first exact hit of this action (note_state_hits), or NO_HIT
         s.actconc[a] = (th != FRIRL_HIP_NO_HIT) ? qcol[th] : tv / tw;
+        s.tv[a] = tv; s.tw[a] = tw;
     }
     __syncthreads();
+    if constexpr (SAMES) { qres.hit = s.hit[apend]; qres.vagc = s.tv[apend]; qres.ws = s.tw[apend]; }
     if (threadIdx.x == 0) {
         int best = 0;
         for (int a = 1; a < A; a++) if (s.actconc[best] < s.actconc[a]) best = a;
