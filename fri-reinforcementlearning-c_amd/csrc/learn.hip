@@ -60,13 +60,16 @@ extern "C" int frirl_hip_learn_plan(int32_t nlive, int32_t mean_rules, int32_t *
     return FRIRL_HIP_OK;
 }
 
+// cartpole's 40 KB of LDS tables leave no room for the cold-state area of 256 one-lane agents per workgroup: at least 2 lanes per agent
+static int learn_min_slices(int A) { return A > 8 ? 2 : 1; }
+
 extern "C" int frirl_hip_learn_supported(int32_t nant, int32_t U, int32_t A, int32_t p, int32_t env_kind)
 {
     if (p > 0 && p != nant) return 0;
     if (opts().learn_persistent == 0) return 0;
     if (env_kind == FRIRL_HIP_ENV_MOUNTAINCAR && nant == 3 && A == 3 && U <= 64) return 1;      // the demos' shapes
     if (env_kind == FRIRL_HIP_ENV_ACROBOT && nant == 5 && A == 3 && U <= 64) return 1;
-    // cartpole (21 actions): 22 conclusions per lane do not fit the register file; it stays with the lane groups of lanes.hip
+    if (env_kind == FRIRL_HIP_ENV_CARTPOLE && nant == 5 && A == 21 && U <= 1024) return 1;      // 22 conclusions: two walks of 11 per step
     return 0;
 }
 
@@ -126,10 +129,11 @@ extern "C" int frirl_hip_learn_run(const frirl_hip_tables *t, const frirl_hip_ru
 #ifdef LEARN_TIMING
     la.timing = learn_timing_buffer();
 #endif
-    const int H = learn_slices(nlive);
+    int H = learn_slices(nlive);
+    if (H < learn_min_slices(agent->A)) H = learn_min_slices(agent->A);
     if (t->nant == 3) frirl_learn_launch_mountaincar(H, t, b, agent, envs, conv, la, s);
     else if (agent->A == 3) { if (H <= 8) frirl_learn_launch_acrobot_lo(H, t, b, agent, envs, conv, la, s); else frirl_learn_launch_acrobot_hi(H, t, b, agent, envs, conv, la, s); }
-    else { set_error("frirl_hip_learn_run: cartpole's 21 actions are not covered"); return FRIRL_HIP_EINVAL; }
+    else { if (H <= 8) frirl_learn_launch_cartpole_lo(H, t, b, agent, envs, conv, la, s); else frirl_learn_launch_cartpole_hi(H, t, b, agent, envs, conv, la, s); }
     return check_launch("frirl_hip_learn_run");
 }
 
@@ -248,7 +252,9 @@ extern "C" int frirl_hip_learn_train(const frirl_hip_tables *t, const frirl_hip_
     long long mean_rules = 0;
     while (n > 0) {
         int32_t H = 0, take = 0;
-        if ((rc = frirl_hip_learn_plan(n, (int32_t)mean_rules, &H, &take)) != 0) return rc;
+        // the plan's cost model counts a rule as 4 conclusions (the 3-action demos): 22 conclusions weigh 5.5 times as much
+        if ((rc = frirl_hip_learn_plan(n, (int32_t)(mean_rules * (agent->A + 1) / 4), &H, &take)) != 0) return rc;
+        if (H < learn_min_slices(agent->A)) { H = learn_min_slices(agent->A); const long fit = learn_lanes() / H; take = (int32_t)(n < fit ? n : fit); }
         hipLaunchKernelGGL(learn_queue_sort_kernel, dim3(1), dim3(LQ_BLOCK), 0, s, qa, take, b->nrules, shift, live);
         if ((rc = frirl_hip_learn_run(t, b, agent, envs, conv, live, take, budget_steps, max_episodes, work, steps_total, workspace, run_bytes, stream)) != 0) return rc;
         launches++;

@@ -131,14 +131,15 @@ template <int NANT, int NA, int KIND, int H, int BITS, int WPS>
 __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la, const frirl_hip_agent ag, const frirl_hip_envs ev,
                                                               const frirl_hip_convergence cv)
 {
-    constexpr int NS = NANT - 1, EPW = FRIRL_WAVE / H, NC = NA + 1;           // NC conclusions per step: A actions at s', Q(s, a)
+    constexpr int NS = NANT - 1, EPW = FRIRL_WAVE / H;                        // NA + 1 conclusions per step: A actions at s', Q(s, a)
     constexpr int FPW = Packed<BITS>::FPW, W = Packed<BITS>::words(NANT);
     constexpr int UR = LEARN_UR;                                        // rules fetched per batch, two batches in flight
     using RecI = typename std::conditional<W == 1, uint32_t, typename std::conditional<W == 2, uint2, uint4>::type>::type;
     // STATIC LDS, so that every address is a compile-time constant: a table entry is read at  8 * index  with the table row's address
     // as the instruction's immediate offset (no base register to add).  Tables have a fixed row stride of 64 entries (6-bit indices).
-    static_assert(BITS == 6, "the LDS tables are laid out for 6-bit universe indices (universes of <= 64 points)");
-    constexpr int TS = 64;
+    static_assert(BITS == 6 || BITS == 10, "the LDS tables are laid out for 6-bit (<= 64 points) or 10-bit (<= 1024 points: cartpole) universe indices");
+    constexpr int TS = 1 << BITS;
+    constexpr int MW = BITS == 6 ? LR_MW : LR_MW / 2;                         // flag words per lane (the 40 KB tables of cartpole leave less LDS)
     constexpr bool LU = KIND != FRIRL_HIP_ENV_CARTPOLE;                          // small tables: the universes in LDS too
     constexpr int NCOLD = 2 * NS + 2 * NANT + 3 + 4;                          // cold per-agent state parked during every sweep (see below)
     __shared__ double tab_s[(LU ? 2 : 1) * NANT * TS];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     __shared__ double udiv[8];                                                // FIVEInit.c:244-248, once instead of per observation
     __shared__ unsigned aidx_s[NA];                                           // universe index of every action value
     extern __shared__ __attribute__((aligned(16))) double cold_s[];          // [LR_WPB * EPW][NCOLD]: dynamic (51 KB at one lane per agent: beyond the static limit)
-    __shared__ uint32_t mask_s[LR_MW * LR_BLOCK];                             // [word][thread]: spread candidates of the sweep (see `thr`)
+    __shared__ uint32_t mask_s[MW * LR_BLOCK];                             // [word][thread]: spread candidates of the sweep (see `thr`)
     static_assert(32 % (2 * UR) == 0, "a flag word is filled by whole loop iterations");
     const int U = la.U, maxR = la.maxR;
     const int lane = threadIdx.x & (FRIRL_WAVE - 1), wave = threadIdx.x / FRIRL_WAVE;
@@ -175,9 +176,6 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
     RecI *Ti_g = reinterpret_cast<RecI *>(la.Ti) + tbase + il * H;                // the group's rule r: [(r / H) * 64 + r % H]
     double *Tq_g = la.Tq + tbase + il * H;
     const auto pk = pin_pow(PowC<NANT>());
-    double ave[NA];
-#pragma unroll
-    for (int a = 0; a < NA; a++) ave[a] = ag.action_ve[a];
 
     auto decode = [&](const RecI &x, double (&c)[NANT]) {
         uint32_t w[W];
@@ -244,13 +242,13 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             if constexpr (FL) {
                 if ((jt & 31) == jtm) {                                        // 32 more rules walked: a full word
                     const int wd = ((jt0 - jt) >> 5) - 1;
-                    if (wd < LR_MW) mask_s[wd * LR_BLOCK + threadIdx.x] = cmask;
+                    if (wd < MW) mask_s[wd * LR_BLOCK + threadIdx.x] = cmask;
                 }
             }
         }
         if constexpr (FL) {
             const int done = jt0 - jt, rem = done & 31;                        // jt0 < 0: nothing walked
-            if (jt0 >= 0 && rem != 0 && (done >> 5) < LR_MW) mask_s[(done >> 5) * LR_BLOCK + threadIdx.x] = cmask << (32 - rem);
+            if (jt0 >= 0 && rem != 0 && (done >> 5) < MW) mask_s[(done >> 5) * LR_BLOCK + threadIdx.x] = cmask << (32 - rem);
         }
     };
     auto for_slice = [&](int R, bool needq, auto &&f) {
@@ -356,57 +354,115 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
         asm volatile("" ::: "memory");
         LT_MARK(1);
 
-        // ---- one pass over this lane's rules: Q(s', a) for every action (frirl_get_best_action, :148) and Q(s, a) of the pending
-        //      update (frirl_update_sarsa.c:357); an exact hit poisons the sums of its own conclusion, which are then not read
-        double sv[NC], sw[NC];
-        unsigned sh[NC];
+        // ---- this lane's rules: Q(s', a) for every action (frirl_get_best_action, :148) and Q(s, a) of the pending update
+        //      (frirl_update_sarsa.c:357); an exact hit poisons the sums of its own conclusion, which are then not read.  Up to 8 actions:
+        //      ONE walk with all A + 1 conclusions in registers.  More (cartpole: 21): the conclusions do not fit the register file at
+        //      once, so the rules are walked in PARTS of <= 11 conclusions each (state part and decode repeated per part: ~10 %); every
+        //      part reduces its conclusions to "best action so far" before the next one starts.
+        double bv = 0.0, swb = 0.0;                                           // greedy: first maximum in action order (max.inl:21), its weight sum
+        int ci = 0;
+        unsigned hit1 = FRIRL_HIP_NO_HIT;                                     // the pending conclusion
+        double vs1 = 0.0, ws1 = 0.0;
+        auto part = [&](auto a0c, auto napc, auto withpc, Pref &pf) {
+            constexpr int A0 = decltype(a0c)::value, NAP = decltype(napc)::value;
+            constexpr bool WITHP = decltype(withpc)::value;
+            constexpr int NCP = NAP + (WITHP ? 1 : 0);
+            double sv[NCP], sw[NCP], pave[NAP];
+            unsigned sh[NCP];
 #pragma unroll
-        for (int i = 0; i < NC; i++) { sv[i] = 0.0; sw[i] = 0.0; sh[i] = FRIRL_HIP_NO_HIT; }
-        if (active) {
-            for_slice_from(pmain, true, [&](int r, const double (&c)[NANT], double cq) {
-                const double e0 = ve2[0] - c[0], g0 = ve1[0] - c[0];
-                double s2 = e0 * e0, s1 = g0 * g0;
+            for (int i = 0; i < NCP; i++) { sv[i] = 0.0; sw[i] = 0.0; sh[i] = FRIRL_HIP_NO_HIT; }
 #pragma unroll
-                for (int k = 1; k < NS; k++) {
-                    const double d2 = ve2[k] - c[k], d1 = ve1[k] - c[k];
-                    s2 = __fma_rn(d2, d2, s2);
-                    s1 = __fma_rn(d1, d1, s1);
-                }
-                const double va = c[NS];
+            for (int a = 0; a < NAP; a++) pave[a] = ag.action_ve[A0 + a];
+            if (active) {
+                for_slice_from(pf, true, [&](int r, const double (&c)[NANT], double cq) {
+                    const double e0 = ve2[0] - c[0];
+                    double s2 = e0 * e0, s1 = 0.0;
+                    if constexpr (WITHP) { const double g0 = ve1[0] - c[0]; s1 = g0 * g0; }
 #pragma unroll
-                for (int a = 0; a < NA; a++) {
-                    const double ea = ave[a] - va;
-                    const double d = __fma_rn(ea, ea, s2);
-                    sh[a] = (d == 0.0) ? (unsigned)r : sh[a];                 // descending walk: the last hit seen is the lowest
-                    const double wi = shepard_w(d, pk);
-                    sv[a] = __fma_rn(wi, cq, sv[a]);
-                    sw[a] = sw[a] + wi;
-                }
-                const double e1 = ve1[NS] - va;
-                const double d = __fma_rn(e1, e1, s1);
-                sh[NA] = (d == 0.0) ? (unsigned)r : sh[NA];
-                const double wi = shepard_w(d, pk);
-                sv[NA] = __fma_rn(wi, cq, sv[NA]);
-                sw[NA] = sw[NA] + wi;
-                return (uint32_t)__double2hiint(thr - wi);                    // sign bit: w_r > thr
-            }, std::true_type());
-            wmain += R;
-        }
-        LT_MARK(2);
-        if (H > 1) {                                                          // the H rule slices of every conclusion, a few conclusions at a time
-            constexpr int CH = 4;
+                    for (int k = 1; k < NS; k++) {
+                        const double d2 = ve2[k] - c[k];
+                        s2 = __fma_rn(d2, d2, s2);
+                        if constexpr (WITHP) { const double d1 = ve1[k] - c[k]; s1 = __fma_rn(d1, d1, s1); }
+                    }
+                    const double va = c[NS];
 #pragma unroll
-            for (int i0 = 0; i0 < NC; i0 += CH) {
-                for (int off = 1; off < H; off <<= 1) {
-                    double tv[CH], tw[CH];
-                    unsigned th[CH];
+                    for (int a = 0; a < NAP; a++) {
+                        const double ea = pave[a] - va;
+                        const double d = __fma_rn(ea, ea, s2);
+                        sh[a] = (d == 0.0) ? (unsigned)r : sh[a];             // descending walk: the last hit seen is the lowest
+                        const double wi = shepard_w(d, pk);
+                        sv[a] = __fma_rn(wi, cq, sv[a]);
+                        sw[a] = sw[a] + wi;
+                    }
+                    if constexpr (WITHP) {
+                        const double e1 = ve1[NS] - va;
+                        const double d = __fma_rn(e1, e1, s1);
+                        sh[NAP] = (d == 0.0) ? (unsigned)r : sh[NAP];
+                        const double wi = shepard_w(d, pk);
+                        sv[NAP] = __fma_rn(wi, cq, sv[NAP]);
+                        sw[NAP] = sw[NAP] + wi;
+                        return (uint32_t)__double2hiint(thr - wi);            // sign bit: w_r > thr
+                    } else {
+                        return 0u;
+                    }
+                }, std::integral_constant<bool, WITHP>());
+            }
+            if (H > 1) {                                                      // the H rule slices of every conclusion, a few conclusions at a time
+                constexpr int CH = 4;
 #pragma unroll
-                    for (int i = 0; i < CH; i++) if (i0 + i < NC) { tv[i] = __shfl_xor(sv[i0 + i], off, FRIRL_WAVE); tw[i] = __shfl_xor(sw[i0 + i], off, FRIRL_WAVE); th[i] = (unsigned)__shfl_xor((int)sh[i0 + i], off, FRIRL_WAVE); }
+                for (int i0 = 0; i0 < NCP; i0 += CH) {
+                    for (int off = 1; off < H; off <<= 1) {
+                        double tv[CH], tw[CH];
+                        unsigned th[CH];
 #pragma unroll
-                    for (int i = 0; i < CH; i++) if (i0 + i < NC) { sv[i0 + i] = sv[i0 + i] + tv[i]; sw[i0 + i] = sw[i0 + i] + tw[i]; sh[i0 + i] = th[i] < sh[i0 + i] ? th[i] : sh[i0 + i]; }
+                        for (int i = 0; i < CH; i++) if (i0 + i < NCP) { tv[i] = __shfl_xor(sv[i0 + i], off, FRIRL_WAVE); tw[i] = __shfl_xor(sw[i0 + i], off, FRIRL_WAVE); th[i] = (unsigned)__shfl_xor((int)sh[i0 + i], off, FRIRL_WAVE); }
+#pragma unroll
+                        for (int i = 0; i < CH; i++) if (i0 + i < NCP) { sv[i0 + i] = sv[i0 + i] + tv[i]; sw[i0 + i] = sw[i0 + i] + tw[i]; sh[i0 + i] = th[i] < sh[i0 + i] ? th[i] : sh[i0 + i]; }
+                    }
                 }
             }
+            if (active) {
+#pragma unroll
+                for (int a = 0; a < NAP; a++) {
+                    const double c = (sh[a] != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(sh[a] / H) * 64 + (sh[a] % H)] : sv[a] / sw[a];
+                    if (A0 + a == 0 || bv < c) { bv = c; ci = A0 + a; swb = sw[a]; }
+                }
+                if constexpr (WITHP) { hit1 = sh[NAP]; vs1 = sv[NAP]; ws1 = sw[NAP]; }
+            }
+        };
+        if constexpr (NA <= 8) {
+            part(std::integral_constant<int, 0>(), std::integral_constant<int, NA>(), std::true_type(), pmain);
+        } else {
+            constexpr int NA1 = (NA + 1) / 2;
+            part(std::integral_constant<int, 0>(), std::integral_constant<int, NA1>(), std::false_type(), pmain);
+            Pref p2 = slice_prefetch(active ? R : 0, true);
+            part(std::integral_constant<int, NA1>(), std::integral_constant<int, NA - NA1>(), std::true_type(), p2);
         }
+        if (active) wmain += R;
+        LT_MARK(2);
+        // Q(s', ax), its weight sum and exact hit for an action that is not the greedy one (an exploratory choice): its own walk
+        auto action_conclusion = [&](int ax, double &v, double &w, unsigned &hh) {
+            const double avx = ag.action_ve[ax];
+            v = 0.0; w = 0.0; hh = FRIRL_HIP_NO_HIT;
+            for_slice(R, true, [&](int r, const double (&c)[NANT], double cq) {
+                const double e0 = ve2[0] - c[0];
+                double s2 = e0 * e0;
+#pragma unroll
+                for (int k = 1; k < NS; k++) { const double d2 = ve2[k] - c[k]; s2 = __fma_rn(d2, d2, s2); }
+                const double ea = avx - c[NS];
+                const double d = __fma_rn(ea, ea, s2);
+                hh = (d == 0.0) ? (unsigned)r : hh;
+                const double wi = shepard_w(d, pk);
+                v = __fma_rn(wi, cq, v);
+                w = w + wi;
+            });
+            for (int off = 1; off < H; off <<= 1) {
+                const double tv = __shfl_xor(v, off, FRIRL_WAVE), tw = __shfl_xor(w, off, FRIRL_WAVE);
+                const unsigned th = (unsigned)__shfl_xor((int)hh, off, FRIRL_WAVE);
+                v = v + tv; w = w + tw; hh = th < hh ? th : hh;
+            }
+            wextra += R;
+        };
         asm volatile("" ::: "memory");
         {
 #pragma unroll
@@ -414,27 +470,18 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
 #pragma unroll
             for (int k = 0; k < NANT; k++) { q_ant[k] = cold[2 * NS + k]; cur_q[k] = cold[2 * NS + NANT + k]; }
             total = cold[2 * NS + 2 * NANT]; prev_reward = cold[2 * NS + 2 * NANT + 1]; reward = cold[2 * NS + 2 * NANT + 2];
-            const int *ci = reinterpret_cast<const int *>(cold + 2 * NS + 2 * NANT + 3);
-            fus = ci[0]; steps = ci[1]; prevR = ci[2]; prev_steps = ci[3]; nep = ci[4]; lsteps = ci[5]; episode = (uint32_t)ci[6]; success = ci[7];
+            const int *cint = reinterpret_cast<const int *>(cold + 2 * NS + 2 * NANT + 3);
+            fus = cint[0]; steps = cint[1]; prevR = cint[2]; prev_steps = cint[3]; nep = cint[4]; lsteps = cint[5]; episode = (uint32_t)cint[6]; success = cint[7];
         }
         LT_MARK(3);
         if (active) {
-            // greedy action: first maximum in action order (max.inl:21)
-            double bv = 0.0;
-            int ci = 0;
-#pragma unroll
-            for (int a = 0; a < NA; a++) {
-                const double c = (sh[a] != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(sh[a] / H) * 64 + (sh[a] % H)] : sv[a] / sw[a];
-                if (a == 0 || bv < c) { bv = c; ci = a; }
-            }
             if (begin) {
                 episode++;
                 const int a0 = e_greedy(ag, ci, (uint32_t)e, episode, 0u);                              // :78-82
                 q_ant[NS] = grid_s[NS * FRIRL_HIP_MAX_GRID + a0];
                 begin = false;
-                double w0 = sw[0];
-#pragma unroll
-                for (int a = 1; a < NA; a++) w0 = (a == a0) ? sw[a] : w0;
+                double w0 = swb;
+                if (a0 != ci) { double v0; unsigned h0; action_conclusion(a0, v0, w0, h0); }
                 thr = (ag.weight_significant * (1.0 - 4e-9)) * w0;
 #pragma unroll
                 for (int k = 0; k < NS; k++) ve1[k] = ve2[k];                                           // (start state, a0) is the next pending point
@@ -452,22 +499,14 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
             } else {
                 const int chosen = e_greedy(ag, ci, (uint32_t)e, episode, (uint32_t)steps + 1u);
                 const bool flags_known = thr > 0.0 && thr < __builtin_inf();                            // this step's flags were taken against a real bound
-                {
-                    double w0 = sw[0];
-#pragma unroll
-                    for (int a = 1; a < NA; a++) w0 = (a == chosen) ? sw[a] : w0;
-                    thr = (ag.weight_significant * (1.0 - 4e-9)) * w0;                                  // (s', a') is the next pending point
-                }
-                double qp = bv;                                                                          // Q(s',a'), frirl_update_sarsa.c:356
+                double qp = bv, w0 = swb;                                                                // Q(s',a'), frirl_update_sarsa.c:356
                 if (chosen != ci) {                                                                      // an exploratory action: its own conclusion
-                    double v = sv[0], w = sw[0];
-                    unsigned hh = sh[0];
-#pragma unroll
-                    for (int a = 1; a < NA; a++) { v = (a == chosen) ? sv[a] : v; w = (a == chosen) ? sw[a] : w; hh = (a == chosen) ? sh[a] : hh; }
-                    qp = (hh != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(hh / H) * 64 + (hh % H)] : v / w;
+                    double v;
+                    unsigned hh;
+                    action_conclusion(chosen, v, w0, hh);
+                    qp = (hh != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(hh / H) * 64 + (hh % H)] : v / w0;
                 }
-                const unsigned hit1 = sh[NA];
-                const double vs1 = sv[NA], ws1 = sw[NA];
+                thr = (ag.weight_significant * (1.0 - 4e-9)) * w0;                                      // (s', a') is the next pending point
                 const double qnow = (hit1 != FRIRL_HIP_NO_HIT) ? Tq_g[(size_t)(hit1 / H) * 64 + (hit1 % H)] : vs1 / ws1;   // Q(s,a), :357
                 cur_q[NS] = grid_s[NS * FRIRL_HIP_MAX_GRID + chosen];                                    // frirl_episode.c:151
 
@@ -568,7 +607,7 @@ __global__ __launch_bounds__(LR_BLOCK, WPS) void learn_kernel(const LearnArgs la
                                 if (w > ag.weight_significant && r != r_skip) { const double t = qdiff * w; Tq_l[(size_t)(r / H) * 64] = qnow + t; }
                             };
                             const int jt0 = (R - h + H - 1) / H - 1;                                    // the walk the flags were taken on
-                            if (group_or(!flags_known || jt0 >= LR_MW * 32)) {
+                            if (group_or(!flags_known || jt0 >= MW * 32)) {
                                 for_slice(R, false, [&](int r, const double (&c)[NANT], double) { move(r, c); });   // every lane its own rules
                                 wextra += R;
                             } else {
@@ -716,7 +755,12 @@ inline void launch_learn_h(int H, const frirl_hip_tables *t, const frirl_hip_rul
     if constexpr (HLO <= 64 && 64 <= HHI) if (H == 64) return launch_learn<N, NA, KIND, 64, BITS, WPS>(t, b, ag, ev, cv, la, s);
 }
 
-// defined in learn_i0.hip (mountaincar), learn_i1.hip (acrobot, 2 .. 8 lanes per agent), learn_i2.hip (acrobot, 16 .. 64)
+// defined in learn_i0.hip (mountaincar), learn_i1.hip (acrobot, 1 .. 8 lanes per agent), learn_i2.hip (acrobot, 16 .. 64),
+// learn_i3.hip / learn_i4.hip (cartpole, 2 .. 8 / 16 .. 64)
+void frirl_learn_launch_cartpole_lo(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                                    const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s);
+void frirl_learn_launch_cartpole_hi(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
+                                    const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s);
 void frirl_learn_launch_mountaincar(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
                                     const frirl_hip_convergence *cv, const frirl::LearnArgs &la, hipStream_t s);
 void frirl_learn_launch_acrobot_lo(int H, const frirl_hip_tables *t, const frirl_hip_rulebases *b, const frirl_hip_agent *ag, const frirl_hip_envs *ev,
