@@ -461,7 +461,7 @@ def learning_and_evaluation(B, w, world, rank):
             legs[nm]["vs_replicas"] = legs[nm]["fp64_issue"]["frac"] / legs["learning"]["fp64_issue"]["frac"]      # counted work per second against the replica leg's
             legs[nm]["vs_replicas_env_steps"] = legs[nm]["value"] / legs["learning"]["value"]
     else:
-        # cartpole (21 actions): one episode per launch through the lane groups of lanes.hip; no work counters in that kernel
+        # shapes the persistent learner does not cover: one episode per launch through the lane groups of lanes.hip; no work counters in that kernel
         lE = 8192
         for name, diversify in (("learning", False), ("learning_diversified", True)):
             start = grid_start_states(dd, lE, device, 1 + rank) if diversify else None

@@ -347,7 +347,8 @@ int frirl_hip_episode_run_lanes(const frirl_hip_tables *t, const frirl_hip_ruleb
  * walk the whole rule base -- normally it visits only the handful of rules the fused sweep flagged as possibly significant, which
  * are not counted); steps_total
  * ([dev][E] int64, or NULL) the environment steps.  Needs the 16-bit index mirror.  Covered shapes: frirl_hip_learn_supported
- * (mountaincar and acrobot: 3 actions, universes of <= 64 points; cartpole's 21 actions stay with frirl_hip_episode_run_lanes).
+ * (the demos' shapes: mountaincar and acrobot -- 3 actions, universes of <= 64 points -- and cartpole -- 21 actions, <= 1024 points: its
+ * rules are walked twice per step, 11 conclusions each; other shapes: frirl_hip_episode_run_lanes).
  * Decisions follow the oracle exactly on the demos (tests/test_hip_learn.py); interpolated Q within the 1e-6 contract (per-lane sums in
  * descending rule order, slices added in butterfly order). */
 int frirl_hip_learn_supported(int32_t nant, int32_t U, int32_t A, int32_t p, int32_t env_kind);

@@ -1,6 +1,4 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r03d_pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -4 gpurun_out/r03d_pytest_gpu.log
-[ $rc -eq 0 ] || exit $rc
-( time timeout -k 10 600 python bench.py ) > gpurun_out/r03d_bench.json 2> gpurun_out/r03d_bench.err; echo "bench rc=$?"; tail -4 gpurun_out/r03d_bench.err
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r03e_pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -4 gpurun_out/r03e_pytest_gpu.log
