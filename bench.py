@@ -18,7 +18,7 @@ rule base until every rule base is complete (replicas of the demo / one start st
 the same with 262 144 agents per GPU, four times what the chip keeps resident: launches stay full until the end of the run;
 the job's report crosses the GPUs once per leg), with a COUNTED FP64-issue roofline (rule visits accumulated by the kernel); "evaluation" = greedy roll-outs of
 65 536 environments on one shared rule base, counted the same way; "other_configs" = the first two legs on BASELINE's other
-configurations (cfg2, cfg3, cfg5; N = 1 only); "cpu_baseline" = the genuine reference on the host cores (rank 0, N = 1,
+configurations (cfg2, cfg3, cfg5; N = 1 only), and for their demos (mountaincar, cartpole) the many-agent learning run as "learning"; "cpu_baseline" = the genuine reference on the host cores (rank 0, N = 1,
 time-boxed).  Every timed leg is followed, outside the timed region, by a PARITY GATE (tests/gates.py): sampled environments
 against the oracle -- the run exits non-zero on a mismatch.
 
@@ -538,6 +538,40 @@ def learning_and_evaluation(B, w, world, rank):
     return legs
 
 
+def learning_other_env(B, env, agents=LEARN_AGENTS):
+    """The learning legs on another demo (N = 1 only, beside the other configurations): `agents` replicas to convergence and the same
+    number of agents with one start state each (200 episodes), through frirl_hip_learn_train; counted FP64-issue fraction as above."""
+    import torch
+    import frirl_amd
+    device = B.device
+    dd = frirl_amd.demo_describe(env)
+    nant, A = dd["nant"], len(dd["action_ve"])
+    wprob, wagent, wenvs = frirl_amd.demo_fresh_batch(env, 64, 1024, device)
+    if not frirl_amd.learn_supported(wprob, wagent):
+        return None
+    frirl_amd.train_persistent(wprob, wagent, wenvs, max_episodes=3, budget=64)          # untimed: loads the code objects
+    del wprob, wenvs
+    out = {}
+    for name, diversify, max_episodes in (("replicas", False, 1000), ("diversified", True, 200)):
+        start = grid_start_states(dd, agents, device, 1) if diversify else None
+        lprob, lagent, lenvs = frirl_amd.demo_fresh_batch(env, agents, 1024, device, start_states=start)
+        B.sync_all()
+        t0 = time.perf_counter()
+        run = frirl_amd.train_persistent(lprob, lagent, lenvs, max_episodes=max_episodes, budget=512)
+        B.sync_all()
+        dt = time.perf_counter() - t0
+        wk = run.work.sum(0).double().tolist()
+        steps = float(run.steps_total.sum().item())
+        slots = wk[0] * (14.4 * (A + 1) + 4.0 * (nant - 1)) + wk[1] * (2.0 * nant + 10.4)
+        out[name] = {"value": steps / dt, "unit": "env-steps/s", "agents": agents, "wall_s": dt, "env_steps": steps, "launches": run.launches,
+                     "agents_converged": float(run.conv.converged.sum().item()), "mean_final_rules": float(lprob.nrules.double().mean().item()),
+                     "agents_with_refused_appends": float(run.conv.full_envs),
+                     "fp64_issue_frac_counted_work": slots / dt / (FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0)}
+        del lprob, lenvs, run
+        torch.cuda.empty_cache()
+    return out
+
+
 def rollout_gate(one, agent, env, ss, rsteps, rrew, sample):
     """Sampled roll-outs against the oracle's frirl_test_run episode (portable trig) on the same rule base."""
     import numpy as np
@@ -657,9 +691,11 @@ def main():
                 rec["env_steps"] = B.env_steps_leg(ow, oprob, oagent, oenvs, max(args.env_steps // 2, 5), 2, name)
                 rec["env_steps"].pop("stats_allreduce", None)
             rec["wall_s_incl_setup"] = round(time.perf_counter() - t0, 1)
-            others[name] = rec
             del oprob, oagent, oenvs, ox
             torch.cuda.empty_cache()
+            if ow.get("env") and ow["env"] != w.get("env") and not args.no_learn:
+                rec["learning"] = learning_other_env(B, ow["env"])          # the demo's many-agent learning run (replicas / one start state each)
+            others[name] = rec
 
     if rank == 0:
         evals = float(E) * R * args.steps * world
