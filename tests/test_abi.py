@@ -113,3 +113,29 @@ def test_shared_and_lane_entry_points_refuse_without_gpu(lib):
                lib.frirl_hip_episode_run_lanes(C.byref(t), C.byref(b1), C.byref(ag), C.byref(ev), 5, addr, 1 << 20, None)):
         assert rc == -1, lib.frirl_hip_last_error()
         assert b"no CPU fallback" in lib.frirl_hip_last_error()
+
+
+def test_learner_launch_plan_and_coverage(lib):
+    """Host-side logic of the persistent learner (no GPU needed: a 256-CU chip is assumed when none is visible): which shapes it
+    covers, and the launch plan -- lanes per agent 1 ... 64, never more agents than are alive or than fill the chip."""
+    MC, CP, AC = 0, 1, 2
+    assert lib.frirl_hip_learn_supported(3, 41, 3, 0, MC) == 1
+    assert lib.frirl_hip_learn_supported(5, 41, 3, 0, AC) == 1
+    assert lib.frirl_hip_learn_supported(5, 1001, 21, 0, CP) == 1          # 21 actions: two walks of 11 conclusions per step
+    assert lib.frirl_hip_learn_supported(5, 41, 3, 3, AC) == 0             # a Shepard power other than nant
+    assert lib.frirl_hip_learn_supported(5, 2001, 21, 0, CP) == 0          # universes beyond the 10-bit index fields
+    assert lib.frirl_hip_learn_supported(4, 41, 3, 0, AC) == 0
+    lanes = 256 * 4 * 2 * 64
+    last_h = 0
+    for n in (1, 63, 2048, 2049, 5000, 16384, 40000, 65536, 65537, 131072, 500000):
+        H, take = C.c_int32(), C.c_int32()
+        assert lib.frirl_hip_learn_plan(n, 200, C.byref(H), C.byref(take)) == 0
+        assert H.value in (1, 2, 4, 8, 16, 32, 64) and 1 <= take.value <= n
+        assert take.value * H.value <= lanes, (n, H.value, take.value)
+        assert take.value == n or take.value == lanes // H.value              # everybody, or a full chip
+        if last_h:
+            assert H.value <= last_h                                          # more agents never get more lanes each
+        last_h = H.value
+    assert lib.frirl_hip_learn_plan(0, 0, C.byref(H), C.byref(take)) != 0
+    a = lib.frirl_hip_learn_workspace_bytes(5, 4096, 512, 3)
+    assert lib.frirl_hip_learn_train_workspace_bytes(5, 4096, 512, 3) >= a + 3 * 4096 * 4 > 0
