@@ -17,7 +17,8 @@ per environment); "learning" / "learning_diversified" = 65 536 agents per GPU le
 rule base until every rule base is complete (replicas of the demo / one start state per agent; "learning_diversified_4x" =
 the same with 262 144 agents per GPU, four times what the chip keeps resident: launches stay full until the end of the run;
 the job's report crosses the GPUs once per leg), with a COUNTED FP64-issue roofline (rule visits accumulated by the kernel); "evaluation" = greedy roll-outs of
-65 536 environments on one shared rule base, counted the same way; "other_configs" = the first two legs on BASELINE's other
+65 536 environments on one shared rule base, counted the same way ("evaluation_16x": a million environments per GPU, the queue-fed
+throughput regime of the same call); "other_configs" = the first two legs on BASELINE's other
 configurations (cfg2, cfg3, cfg5; N = 1 only), and for their demos (mountaincar, cartpole) the many-agent learning run as "learning"; "cpu_baseline" = the genuine reference on the host cores (rank 0, N = 1,
 time-boxed).  Every timed leg is followed, outside the timed region, by a PARITY GATE (tests/gates.py): sampled environments
 against the oracle -- the run exits non-zero on a mismatch.
@@ -535,6 +536,26 @@ def learning_and_evaluation(B, w, world, rank):
                                         "fp64_issue_frac": sweeps * Rone * (14.4 * A + 2.0 * (nant - 1)) / pdt / (FP64_VECTOR_PEAK_TFLOPS * 1e12 / 2.0),
                                         "how": "the same call 10 times, alternating between two HIP streams: one call's straggler tail overlaps the next call's bulk"},
                           "note": "frirl_hip_rollout_shared: whole greedy episodes from perturbed start states on one shared rule base, no updates; value = average of 5 back-to-back calls on one stream"}
+    # the same call with sixteen times the environments: the launch is queue-fed (four waves per SIMD), the few never-ending episodes no longer
+    # set the call's length -- the throughput regime of the roll-out kernels, next to the 65 536-environment call above
+    Qb = 16 * Qn
+    sb = (vd + (torch.rand((Qb, ns), dtype=torch.float64, device=device, generator=g) - 0.5) * 0.2 * (hi - lo)).clamp(lo, hi).contiguous()
+    one.rollout_shared(eagent, Qb, start_states=sb)
+    B.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        bsteps, brew, bsucc, _ = one.rollout_shared(eagent, Qb, start_states=sb)
+    B.sync_all()
+    bdt = D.max_over_ranks(time.perf_counter() - t0, device) / 3
+    bt = torch.tensor([float(bsteps.sum().item())], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(bt)
+    bsweeps = bt[0].item() + Qb * world
+    bgate = rollout_gate(one, eagent, env, sb, bsteps, brew, [0, Qb // 3, Qb - 1] + [int(i) for i in torch.topk(bsteps, 2).indices.tolist()])
+    legs["evaluation_16x"] = {"value": bt[0].item() / bdt, "unit": "env-steps/s", "environments": Qb * world, "rules": Rone, "wall_s": bdt, "env_steps": bt[0].item(),
+                              "parity_gate": bgate,
+                              "fp64_issue": issue_record(bsweeps * Rone * (14.4 * A + 2.0 * (nant - 1)), bdt,
+                                                         {"rule_visits": bsweeps * Rone, "slots_per_visit": 14.4 * A + 2.0 * (nant - 1)})}
     return legs
 
 
