@@ -112,3 +112,21 @@ def test_training_loop_on_the_device_with_thousands_of_agents(env, max_episodes,
         assert ok == int(converged[e]), (e, ok, converged[e])
         assert fr.total_steps == total[e], (e, fr.total_steps, total[e])
         check_agent_against_oracle(fr, prob, envs, e)
+
+
+@pytest.mark.parametrize("env", ["mountaincar", "acrobot", "cartpole"])
+def test_launches_of_a_few_steps_change_nothing(env):
+    """A work budget of 5 steps per launch: thousands of launches, every agent stopped and resumed every few steps -- the carried pending
+    point, the spread flags' bound and the on-grid shortcut all start from "unknown" each time (the slow paths), and the result is
+    still the oracle's run, step for step."""
+    import torch
+    dev = torch.device("cuda", 0)
+    fr = ob.Frirl(env, trig_mode=1)
+    assert fr.run() == 1
+    prob, agent, envs = frirl_amd.demo_fresh_batch(env, 3, 512, dev)
+    run = frirl_amd.train_persistent(prob, agent, envs, budget=5)
+    torch.cuda.synchronize()
+    assert (run.conv.converged == 1).all() and (run.steps_total == fr.total_steps).all()
+    assert run.launches > fr.total_steps // 12
+    for e in range(3):
+        check_agent_against_oracle(fr, prob, envs, e)
