@@ -21,6 +21,16 @@
 // LDS copy of the tables (rb[e][k][r] == ve[k][uidx[e][k][r]] exactly, five_add_rule.c:76-81): 12 B per rule and step from
 // HBM / L2 instead of 48.  Rules are walked from the highest index down so that "the lowest exact hit" is simply the last one
 // seen.  Sums: per lane in (descending) index order, slices added in butterfly order -- interpolated values, <= 1e-6 contract.
+//
+// What a step does NOT repeat (round 3, second half; each measured in profiles/r03d_learner.md):
+//  * the weighted spread visits only rules the fused sweep FLAGGED as possibly significant (one bit per rule against a lower bound
+//    of the weight sum that is known before the sweep: `thr`), not every rule a second time;
+//  * the pending point (s, a) is the (s', a') of the step before: its VE values, packed indices and "is a grid point" flag are
+//    carried, not re-derived; frirl_check_possible_states of a grid point is the point itself;
+//  * a launch ends an agent after the WORK of `budget` mean-agent steps, so that the waves of the large rule bases do not outlast
+//    the others (all waves of a launch are resident together: the launch lasts as long as its slowest wave);
+//  * more than 8 actions (cartpole: 21): the A + 1 conclusions do not fit the register file at once; the rules are walked in parts of
+//    <= 11 conclusions, each part reduced to "best action so far" before the next (`part`).
 #include "sweeps.h"
 #include "envs.h"
 #include <type_traits>
