@@ -3,7 +3,7 @@
 (tools/exp/build_learn_variant.sh timing -DLEARN_TIMING; FRIRL_HIP_LIB_OVERRIDE=.../libfrirl_hip_timing.so).
    python tools/learn_sections.py [env] [E] [rep|div] [budget] [max_episodes] [launches] [opt=value ...]
 Prints, per launch, the share of wave cycles per section of the step."""
-import ctypes as C, json, os, sys
+import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, frirl_amd
 
@@ -26,8 +26,12 @@ names = ["env+observe", "park", "sweep", "butterfly+unpark", "greedy+Q", "bounda
 buf = (C.c_ulonglong * 16)()
 L.frirl_hip_learn_timing(buf)
 last = [0]
+tlast = [None]
 def on_chunk(i, live, conv):
     torch.cuda.synchronize()
+    now = time.perf_counter()
+    wall = now - tlast[0] if tlast[0] is not None else float("nan")
+    tlast[0] = now
     L.frirl_hip_learn_timing(buf)
     t = [buf[k] for k in range(9)]
     tot = sum(t) or 1
@@ -37,6 +41,9 @@ def on_chunk(i, live, conv):
     while H < 64 and n * 2 * H <= 131072: H *= 2
     wave_steps = (st - last[0]) / (64 // H)
     last[0] = st
-    print(json.dumps({"launch": i, "live": n, "mean_rules": round(float(prob.nrules[live.long()].float().mean()), 1), "cycles_per_wave_step": round(tot / max(wave_steps, 1)),
+    waves = (n * H + 63) // 64
+    print(json.dumps({"launch": i, "live": n, "wall_ms": round(wall * 1e3, 2), "waves": waves,
+                      "mean_wave_busy_ms_at_1p9GHz": round(tot / max(waves, 1) / 1.9e9 * 1e3, 2), "mean_rules": round(float(prob.nrules[live.long()].float().mean()), 1), "cycles_per_wave_step": round(tot / max(wave_steps, 1)),
                       "share": {nm: round(x / tot, 3) for nm, x in zip(names, t)}}))
+torch.cuda.synchronize(); tlast[0] = time.perf_counter()
 frirl_amd.train_persistent(prob, agent, envs, max_episodes=max_episodes, budget=budget, on_chunk=on_chunk)
